@@ -1,0 +1,106 @@
+"""ctypes bindings of the two native libraries.  No arithmetic lives here.
+
+libamplisolve_hip.so is the product's compute path; if it is missing or no
+MI355X is visible, every compute call raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(PKG, "lib", "libamplisolve_hip.so")
+HOST_LIB_PATH = os.path.join(PKG, "lib", "libamplisolve_host.so")
+
+vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+
+class AmpliError(RuntimeError):
+    pass
+
+
+class AccTable(C.Structure):
+    """mirror of ampli_acc_table (include/amplisolve_hip.h)"""
+    _fields_ = [("P", i64), ("snt", vp), ("srd", vp), ("cnt", vp), ("nrec", vp), ("gm_n", vp),
+                ("gm_first", vp), ("gm_first_af", vp), ("gm_rest", vp)]
+
+
+class Call(C.Structure):
+    """mirror of ampli_call"""
+    _fields_ = [("sample", i32), ("record", i32), ("alt", i32), ("pad", i32), ("q_fw", C.c_double),
+                ("q_bw", C.c_double), ("af", f32), ("af_fw", f32), ("af_bw", f32), ("pad2", f32)]
+
+
+# every symbol include/amplisolve_hip.h declares: (restype, argtypes)
+HIP_SYMBOLS = {
+    "ampli_abi_version": (C.c_int, []),
+    "ampli_strerror": (C.c_char_p, [C.c_int]),
+    "ampli_device_count": (C.c_int, []),
+    "ampli_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "ampli_ctx_destroy": (None, [vp]),
+    "ampli_last_error": (C.c_char_p, [vp]),
+    "ampli_sync": (C.c_int, [vp]),
+    "ampli_stream": (vp, [vp]),
+    "ampli_pinned_alloc": (C.c_int, [sz, C.POINTER(vp)]),
+    "ampli_pinned_free": (C.c_int, [vp]),
+    "ampli_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "ampli_dev_free": (C.c_int, [vp, vp]),
+    "ampli_copy_h2d": (C.c_int, [vp, vp, vp, sz]),
+    "ampli_copy_d2h": (C.c_int, [vp, vp, vp, sz]),
+    "ampli_memset_d": (C.c_int, [vp, vp, C.c_int, sz]),
+    "ampli_event_create": (C.c_int, [C.POINTER(vp)]),
+    "ampli_event_destroy": (C.c_int, [vp]),
+    "ampli_event_record": (C.c_int, [vp, vp]),
+    "ampli_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
+    "ampli_acc_bytes": (sz, [i64]),
+    "ampli_acc_bind": (C.c_int, [vp, i64, C.POINTER(AccTable)]),
+    "ampli_error_reduce": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, C.POINTER(AccTable)]),
+    "ampli_acc_merge": (C.c_int, [vp, C.POINTER(AccTable), C.POINTER(AccTable), i32]),
+    "ampli_acc_regions": (C.c_int, [i64, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "ampli_gm_merge": (C.c_int, [vp, C.POINTER(AccTable), vp, i32]),
+    "ampli_error_finalize": (C.c_int, [vp, C.POINTER(AccTable), f32, i32, vp, vp, vp, vp, vp, vp]),
+    "ampli_poisson_call": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
+    "ampli_score_batch": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
+    "ampli_roundtrip_batch": (C.c_int, [vp, vp, i64, vp]),
+    "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),
+    "ampli_synth_ref": (C.c_int, [vp, vp, i64, u64]),
+    "ampli_set_tuning": (C.c_int, [vp, i32, i32]),
+}
+
+HOST_SYMBOLS = {
+    "ampli_host_synth_fill": (C.c_int, [vp, i64, i32, i32, u64, i32, i32]),
+    "ampli_host_synth_ref": (C.c_int, [vp, i64, u64]),
+    "ampli_host_text_roundtrip_batch": (None, [vp, i64, vp]),
+    "ampli_host_af_limit": (i32, [i32]),
+    "ampli_host_prefilter_nocall": (C.c_int, [i32, i32, f32]),
+}
+
+_hip = None
+_host = None
+
+
+def _bind(lib, table):
+    for name, (res, args) in table.items():
+        fn = getattr(lib, name)  # AttributeError = missing export: let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def hip_lib():
+    """Load libamplisolve_hip.so (needs the ROCm runtime, not a GPU, to load)."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise AmpliError(f"{HIP_LIB_PATH} is not built: run `python -m amplisolve_amd.build`; there is no CPU fallback")
+        _hip = _bind(C.CDLL(HIP_LIB_PATH), HIP_SYMBOLS)
+    return _hip
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise AmpliError(f"{HOST_LIB_PATH} is not built: run `python -m amplisolve_amd.build`")
+        _host = _bind(C.CDLL(HOST_LIB_PATH), HOST_SYMBOLS)
+    return _host

@@ -1,0 +1,241 @@
+"""Thin Python harness over the C ABI of libamplisolve_hip.so.
+
+torch is used only for plumbing: device memory (tensors), the current HIP
+stream and torch.distributed.  Every number comes out of the HIP kernels; when
+the library or the GPU is missing the calls raise AmpliError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+from ._lib import AccTable, AmpliError, Call, hip_lib
+
+NT = "ACGT"
+POISSON_FULL = 0
+POISSON_PREFILTER = 1
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Acc:
+    """Accumulator table (ampli_acc_table) living in one device buffer."""
+
+    def __init__(self, ctx: "Context", P: int, buf=None):
+        import torch
+
+        lib = ctx.lib
+        self.P = int(P)
+        nbytes = lib.ampli_acc_bytes(self.P)
+        self.buf = buf if buf is not None else torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)
+        assert self.buf.numel() >= nbytes and self.buf.data_ptr() % 256 == 0
+        self.struct = AccTable()
+        ctx._check(lib.ampli_acc_bind(_ptr(self.buf), self.P, C.byref(self.struct)))
+        base = self.buf.data_ptr()
+
+        def view(ptr, dtype, shape):
+            n = 1
+            for d in shape:
+                n *= d
+            off = ptr - base
+            return self.buf[off: off + n * torch.empty(0, dtype=dtype).element_size()].view(dtype).view(*shape)
+
+        s = self.struct
+        P_ = self.P
+        self.snt = view(s.snt, torch.float64, (2, 4, P_))
+        self.srd = view(s.srd, torch.int64, (2, 4, P_))
+        self.cnt = view(s.cnt, torch.int32, (4, P_))
+        self.nrec = view(s.nrec, torch.int32, (P_,))
+        self.gm_n = view(s.gm_n, torch.int32, (4, P_))
+        self.gm_first = view(s.gm_first, torch.int32, (4, P_))
+        self.gm_first_af = view(s.gm_first_af, torch.float32, (4, P_))
+        self.gm_rest = view(s.gm_rest, torch.float32, (4, P_))
+
+    def planes(self):
+        return dict(snt=self.snt, srd=self.srd, cnt=self.cnt, nrec=self.nrec, gm_n=self.gm_n,
+                    gm_first=self.gm_first, gm_first_af=self.gm_first_af, gm_rest=self.gm_rest)
+
+
+@dataclass
+class ErrorTable:
+    rate: "object"          # [2,4,P] float32
+    code: "object"          # [4,P] uint8
+    thr: "object"           # [2,4,P] float32 (after the text round trip)
+    germ_val: "object"      # [4,P] float32
+    germ_present: "object"  # [4,P] uint8
+    flags: "object"         # [1] int32
+
+
+class Context:
+    def __init__(self, device: int = 0, own_stream: bool = False):
+        import torch
+
+        self.lib = hip_lib()
+        if self.lib.ampli_device_count() <= 0 or not torch.cuda.is_available():
+            raise AmpliError("no MI355X visible: libamplisolve_hip.so has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        stream = None if own_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        h = C.c_void_p()
+        rc = self.lib.ampli_ctx_create(device, stream, C.byref(h))
+        if rc != 0:
+            raise AmpliError(f"ampli_ctx_create: {self.lib.ampli_strerror(rc).decode()}")
+        self.h = h
+        self.own_stream = own_stream
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ampli_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            detail = self.lib.ampli_last_error(self.h).decode() if getattr(self, "h", None) else ""
+            raise AmpliError(f"{self.lib.ampli_strerror(rc).decode()} ({rc}): {detail}")
+
+    def sync(self):
+        self._check(self.lib.ampli_sync(self.h))
+
+    def set_tuning(self, reduce_splits: int = 0):
+        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, 0))
+
+    # ---- events on the context's stream -------------------------------------------------
+    def event(self):
+        ev = C.c_void_p()
+        self._check(self.lib.ampli_event_create(C.byref(ev)))
+        return ev
+
+    def record(self, ev):
+        self._check(self.lib.ampli_event_record(self.h, ev))
+
+    def elapsed_ms(self, a, b) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ampli_event_elapsed_ms(a, b, C.byref(ms)))
+        return float(ms.value)
+
+    # ---- kernels ---------------------------------------------------------------------
+    def new_acc(self, P: int) -> Acc:
+        return Acc(self, P)
+
+    def error_reduce(self, recs, P: int, C_value: float = 0.002, cov: int = 100, E: int = 0, dup_off=None,
+                     first_sample: int = 0, acc: Acc | None = None) -> Acc:
+        import torch
+
+        assert recs.dtype == torch.int32 and recs.is_cuda and recs.is_contiguous()
+        S = recs.shape[0]
+        assert recs.numel() == S * (P + E) * 8
+        if acc is None:
+            acc = self.new_acc(P)
+        self._check(self.lib.ampli_error_reduce(self.h, _ptr(recs), P, E, _ptr(dup_off), S, first_sample,
+                                                C_value, cov, C.byref(acc.struct)))
+        return acc
+
+    def acc_merge(self, parts: list[Acc], dst: Acc | None = None) -> Acc:
+        if dst is None:
+            dst = self.new_acc(parts[0].P)
+        arr = (AccTable * len(parts))(*[p.struct for p in parts])
+        self._check(self.lib.ampli_acc_merge(self.h, C.byref(dst.struct), arr, len(parts)))
+        return dst
+
+    def regions(self, P: int):
+        """(sum_bytes, gm_offset, gm_bytes) of a table buffer (ampli_acc_regions)."""
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self._check(self.lib.ampli_acc_regions(P, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def gm_merge(self, dst: Acc, regions, nparts: int):
+        """regions: uint8 tensor holding nparts gathered gm regions back to back."""
+        self._check(self.lib.ampli_gm_merge(self.h, C.byref(dst.struct), _ptr(regions), nparts))
+
+    def error_finalize(self, acc: Acc, C_value: float = 0.002, cov: int = 100, out: ErrorTable | None = None) -> ErrorTable:
+        import torch
+
+        P = acc.P
+        if out is None:
+            d = self.device
+            out = ErrorTable(rate=torch.empty((2, 4, P), dtype=torch.float32, device=d),
+                             code=torch.empty((4, P), dtype=torch.uint8, device=d),
+                             thr=torch.empty((2, 4, P), dtype=torch.float32, device=d),
+                             germ_val=torch.empty((4, P), dtype=torch.float32, device=d),
+                             germ_present=torch.empty((4, P), dtype=torch.uint8, device=d),
+                             flags=torch.zeros((1,), dtype=torch.int32, device=d))
+        self._check(self.lib.ampli_error_finalize(self.h, C.byref(acc.struct), C_value, cov, _ptr(out.rate), _ptr(out.code),
+                                                  _ptr(out.thr), _ptr(out.germ_val), _ptr(out.germ_present), _ptr(out.flags)))
+        return out
+
+    def poisson_call(self, trecs, P: int, thr, ref_code, cov: int = 100, mode: int = POISSON_PREFILTER, E: int = 0,
+                     ext_pos=None, call_mask=None, capacity: int = 0, dense_q: bool = False, dense_af: bool = False,
+                     calls_buf=None, n_calls=None):
+        import torch
+
+        assert trecs.dtype == torch.int32 and trecs.is_cuda and trecs.is_contiguous()
+        T = trecs.shape[0]
+        R = P + E
+        assert trecs.numel() == T * R * 8
+        d = self.device
+        if call_mask is None:
+            call_mask = torch.empty((T, R), dtype=torch.uint8, device=d)
+        q = torch.empty((T, R, 4, 2), dtype=torch.float64, device=d) if dense_q else None
+        af = torch.empty((T, R, 4, 3), dtype=torch.float32, device=d) if dense_af else None
+        if capacity > 0 and calls_buf is None:
+            calls_buf = torch.empty((capacity * C.sizeof(Call),), dtype=torch.uint8, device=d)
+        if (capacity > 0 or n_calls is not None) and n_calls is None:
+            n_calls = torch.zeros((1,), dtype=torch.int64, device=d)
+        self._check(self.lib.ampli_poisson_call(self.h, _ptr(trecs), P, E, _ptr(ext_pos), T, _ptr(thr), _ptr(ref_code), cov,
+                                                mode, _ptr(call_mask), _ptr(calls_buf), capacity, _ptr(n_calls), _ptr(q), _ptr(af)))
+        return dict(call_mask=call_mask, q=q, af=af, calls_buf=calls_buf, n_calls=n_calls)
+
+    def read_calls(self, res) -> list[dict]:
+        """Copy the compact call list to the host, sorted into the reference's emission order."""
+        import numpy as np
+
+        n = int(res["n_calls"].item())
+        cap = res["calls_buf"].numel() // C.sizeof(Call)
+        if n > cap:
+            raise AmpliError(f"call list capacity exceeded: {n} > {cap}")
+        raw = res["calls_buf"][: n * C.sizeof(Call)].cpu().numpy().tobytes()
+        dt = np.dtype([("sample", "<i4"), ("record", "<i4"), ("alt", "<i4"), ("pad", "<i4"), ("q_fw", "<f8"),
+                       ("q_bw", "<f8"), ("af", "<f4"), ("af_fw", "<f4"), ("af_bw", "<f4"), ("pad2", "<f4")])
+        a = np.frombuffer(raw, dtype=dt)
+        a = a[np.lexsort((a["alt"], a["record"], a["sample"]))]
+        return a
+
+    def score_batch(self, k, rd, err):
+        import torch
+
+        n = k.numel()
+        q = torch.empty(n, dtype=torch.float64, device=self.device)
+        p = torch.empty(n, dtype=torch.float64, device=self.device)
+        self._check(self.lib.ampli_score_batch(self.h, _ptr(k), _ptr(rd), _ptr(err), n, _ptr(q), _ptr(p)))
+        return q, p
+
+    def roundtrip_batch(self, x):
+        import torch
+
+        out = torch.empty_like(x)
+        self._check(self.lib.ampli_roundtrip_batch(self.h, _ptr(x), x.numel(), _ptr(out)))
+        return out
+
+    def synth_fill(self, P: int, n_samples: int, first_sample: int = 0, seed: int = 0xA3F15017, depth: int = 2000,
+                   tumour: bool = False, out=None):
+        import torch
+
+        if out is None:
+            out = torch.empty((n_samples, P, 8), dtype=torch.int32, device=self.device)
+        self._check(self.lib.ampli_synth_fill(self.h, _ptr(out), P, n_samples, first_sample, seed, depth, int(tumour)))
+        return out
+
+    def synth_ref(self, P: int, seed: int = 0xA3F15017):
+        import torch
+
+        out = torch.empty((P,), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.ampli_synth_ref(self.h, _ptr(out), P, seed))
+        return out

@@ -1,0 +1,949 @@
+// amplisolve_amd/csrc/ampli_kernels.hip -- HIP kernels + C ABI of libamplisolve_hip.so (gfx950, wave64).
+//
+// Kernels (all HBM-bound integer / scalar-FP work, no MFMA):
+//   error_reduce_kernel   EE:1149-1296 (+clones), EE:1565-1631 (+clones)   32 B read per (position, sample)
+//   acc_merge_kernel      ordered combine of partial accumulator tables
+//   error_finalize_kernel EE:1659-1714 (+clones), sentinel rule EE:1260/1318/1374/1431, text round trip EE:1704->VC:889
+//   poisson_call_kernel   VC:752-898 (+clones), VC:3721-3884                32 B read per (position, tumour)
+// See include/amplisolve_hip.h for the data layout and DESIGN.md for the rooflines.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/amplisolve_hip.h"
+#include "ampli_math.h"
+#include "ampli_synth.h"
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct ampli_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    void *ws = nullptr; // workspace for partial accumulator tables
+    size_t ws_bytes = 0;
+    int reduce_splits = 0; // 0 = auto
+    int n_cu = 256;
+};
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            if (ctx) (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            return AMPLI_E_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+static int fail(ampli_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+extern "C" int ampli_abi_version(void) { return AMPLI_ABI_VERSION; }
+
+extern "C" const char *ampli_strerror(int code)
+{
+    switch (code) {
+    case AMPLI_OK: return "ok";
+    case AMPLI_E_INVALID: return "invalid argument";
+    case AMPLI_E_HIP: return "HIP runtime error (no MI355X visible, or a call failed)";
+    case AMPLI_E_NOMEM: return "out of memory";
+    case AMPLI_E_ENVELOPE: return "accumulators left the exactness envelope";
+    case AMPLI_E_CAPACITY: return "call list capacity exceeded";
+    case AMPLI_E_RANGE: return "count outside the integer envelope (>= 2^24)";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int ampli_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **out)
+{
+    if (!out) return AMPLI_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return AMPLI_E_HIP;
+    if (device_ordinal < 0 || device_ordinal >= n) return AMPLI_E_INVALID;
+    ampli_ctx *ctx = new (std::nothrow) ampli_ctx();
+    if (!ctx) return AMPLI_E_NOMEM;
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return AMPLI_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return AMPLI_E_HIP; }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return AMPLI_OK;
+}
+
+extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *ampli_last_error(ampli_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" void *ampli_stream(ampli_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int ampli_sync(ampli_ctx *ctx)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_pinned_alloc(size_t bytes, void **out)
+{
+    if (!out) return AMPLI_E_INVALID;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? AMPLI_OK : AMPLI_E_NOMEM;
+}
+extern "C" int ampli_pinned_free(void *p) { return hipHostFree(p) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP; }
+
+extern "C" int ampli_dev_alloc(ampli_ctx *ctx, size_t bytes, void **d_out)
+{
+    if (!ctx || !d_out) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(d_out, bytes ? bytes : 1) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "hipMalloc failed");
+    return AMPLI_OK;
+}
+extern "C" int ampli_dev_free(ampli_ctx *ctx, void *d_p)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipFree(d_p));
+    return AMPLI_OK;
+}
+extern "C" int ampli_copy_h2d(ampli_ctx *ctx, void *d_dst, const void *src, size_t bytes)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return AMPLI_OK;
+}
+extern "C" int ampli_copy_d2h(ampli_ctx *ctx, void *dst, const void *d_src, size_t bytes)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return AMPLI_OK;
+}
+extern "C" int ampli_memset_d(ampli_ctx *ctx, void *d_dst, int byte, size_t bytes)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipMemsetAsync(d_dst, byte, bytes, ctx->stream));
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_event_create(void **ev)
+{
+    if (!ev) return AMPLI_E_INVALID;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return AMPLI_E_HIP;
+    *ev = (void *)e;
+    return AMPLI_OK;
+}
+extern "C" int ampli_event_destroy(void *ev) { return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP; }
+extern "C" int ampli_event_record(ampli_ctx *ctx, void *ev)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
+    return AMPLI_OK;
+}
+extern "C" int ampli_event_elapsed_ms(void *a, void *b, float *ms)
+{
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return AMPLI_E_HIP;
+    return hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP;
+}
+
+extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t)
+{
+    if (!ctx || reduce_sample_splits < 0) return AMPLI_E_INVALID;
+    ctx->reduce_splits = reduce_sample_splits;
+    return AMPLI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// accumulator table layout
+// ---------------------------------------------------------------------------
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// every plane starts 256-byte aligned
+static void acc_offsets(int64_t P, size_t off[9])
+{
+    size_t o = 0;
+    off[0] = o; o = align_up(o + (size_t)P * 8 * sizeof(double), 256);   // snt
+    off[1] = o; o = align_up(o + (size_t)P * 8 * sizeof(int64_t), 256);  // srd
+    off[2] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // cnt
+    off[3] = o; o = align_up(o + (size_t)P * 1 * sizeof(int32_t), 256);  // nrec
+    off[4] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // gm_n
+    off[5] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // gm_first
+    off[6] = o; o = align_up(o + (size_t)P * 4 * sizeof(float), 256);    // gm_first_af
+    off[7] = o; o = align_up(o + (size_t)P * 4 * sizeof(float), 256);    // gm_rest
+    off[8] = o;
+}
+
+extern "C" size_t ampli_acc_bytes(int64_t P)
+{
+    if (P <= 0) return 0;
+    size_t off[9];
+    acc_offsets(P, off);
+    return off[8];
+}
+
+extern "C" int ampli_acc_bind(void *base, int64_t P, ampli_acc_table *out)
+{
+    if (!base || !out || P <= 0) return AMPLI_E_INVALID;
+    size_t off[9];
+    acc_offsets(P, off);
+    char *b = (char *)base;
+    out->P = P;
+    out->snt = (double *)(b + off[0]);
+    out->srd = (int64_t *)(b + off[1]);
+    out->cnt = (int32_t *)(b + off[2]);
+    out->nrec = (int32_t *)(b + off[3]);
+    out->gm_n = (int32_t *)(b + off[4]);
+    out->gm_first = (int32_t *)(b + off[5]);
+    out->gm_first_af = (float *)(b + off[6]);
+    out->gm_rest = (float *)(b + off[7]);
+    return AMPLI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-lane accumulator for one position (all 4 nucleotides)
+// ---------------------------------------------------------------------------
+struct LaneAcc {
+    double snt[2][4];
+    long long srd[2][4];
+    int cnt[4];
+    int nrec;
+    int gm_n[4];
+    int gm_first[4];
+    float gm_first_af[4];
+    float gm_rest[4];
+};
+
+__device__ __forceinline__ void lane_acc_init(LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        a.snt[0][nt] = 0.0; a.snt[1][nt] = 0.0;
+        a.srd[0][nt] = 0; a.srd[1][nt] = 0;
+        a.cnt[nt] = 0;
+        a.gm_n[nt] = 0;
+        a.gm_first[nt] = 0x7fffffff;
+        a.gm_first_af[nt] = 0.0f;
+        a.gm_rest[nt] = -INFINITY;
+    }
+    a.nrec = 0;
+}
+
+// One record of one sample at this lane's position.  r0 = {Afw,Cfw,Gfw,Tfw}, r1 = {Ars,Crs,Grs,Trs}.
+__device__ __forceinline__ void visit_record(LaneAcc &a, const int4 r0, const int4 r1, const int sample,
+                                             const float C, const int cov)
+{
+    const bool present = r0.x != AMPLI_ABSENT;
+    const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
+    const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
+    const int FW = fw[0] + fw[1] + fw[2] + fw[3];  // EE:1175
+    const int BW = bw[0] + bw[1] + bw[2] + bw[3];  // EE:1176
+    const int RD = FW + BW;                        // ASEQ RD column (host guarantees RD == A+C+G+T)
+    const bool covok = present && FW >= cov && BW >= cov; // EE:1595, EE:1251 (cov >= 1)
+    a.nrec += present ? 1 : 0;                     // Value_Hash.count(key), EE:1659
+    if (!__any(covok)) return;                     // wave-uniform: nothing below can change state
+
+    // AF <= 0.05 as an integer bound (ampli_math.h); fp form for counts beyond exact floats
+    const bool big = RD >= AMPLI_COUNT_LIMIT;
+    const int lim_fw = ampli_af_limit(FW), lim_bw = ampli_af_limit(BW), lim_rd = ampli_af_limit(RD);
+    // EE:1597,1599: float(RD_s)*float(C), an fp32 product widened to double
+    const double prod_fw = (double)((float)FW * C);
+    const double prod_bw = (double)((float)BW * C);
+    const float rdf = (float)RD;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        bool g_fw = fw[nt] <= lim_fw, g_bw = bw[nt] <= lim_bw, g_tot = (fw[nt] + bw[nt]) <= lim_rd;
+        if (big) { // never taken for real panels; keeps the literal semantics at >= 2^24 reads
+            g_fw = ampli_af_gate_fp(fw[nt], FW);
+            g_bw = ampli_af_gate_fp(bw[nt], BW);
+            g_tot = ampli_af_gate_fp(fw[nt] + bw[nt], RD);
+        }
+        if (covok && g_fw && g_bw) { // EE:1595
+            a.snt[0][nt] = a.snt[0][nt] + (double)fw[nt] + prod_fw; // EE:1597
+            a.srd[0][nt] += FW;                                     // EE:1598
+            a.snt[1][nt] = a.snt[1][nt] + (double)bw[nt] + prod_bw; // EE:1599
+            a.srd[1][nt] += BW;                                     // EE:1600
+            a.cnt[nt] += 1;                                         // EE:1606
+        }
+        if (covok && g_tot) { // EE:1251 (+ clones at 1309, 1365, 1422)
+            const float af = (float)(fw[nt] + bw[nt]) / rdf; // EE:1229-1232
+            if (a.gm_n[nt] == 0) {
+                a.gm_first[nt] = sample;
+                a.gm_first_af[nt] = af;
+            } else if (a.gm_rest[nt] <= af) { // EE:1266
+                a.gm_rest[nt] = af;
+            }
+            a.gm_n[nt] += 1;
+        }
+    }
+}
+
+// L = L (+) R, L covering the earlier samples
+__device__ __forceinline__ void lane_acc_merge(LaneAcc &L, const LaneAcc &R)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        L.snt[0][nt] += R.snt[0][nt]; L.snt[1][nt] += R.snt[1][nt];
+        L.srd[0][nt] += R.srd[0][nt]; L.srd[1][nt] += R.srd[1][nt];
+        L.cnt[nt] += R.cnt[nt];
+        if (R.gm_n[nt] != 0) {
+            if (L.gm_n[nt] == 0) {
+                L.gm_first[nt] = R.gm_first[nt];
+                L.gm_first_af[nt] = R.gm_first_af[nt];
+                L.gm_rest[nt] = R.gm_rest[nt];
+            } else {
+                float m = L.gm_rest[nt];
+                if (m <= R.gm_first_af[nt]) m = R.gm_first_af[nt];
+                if (m <= R.gm_rest[nt]) m = R.gm_rest[nt];
+                L.gm_rest[nt] = m;
+            }
+            L.gm_n[nt] += R.gm_n[nt];
+        }
+    }
+    L.nrec += R.nrec;
+}
+
+struct AccPtrs {
+    double *snt; long long *srd; int *cnt; int *nrec; int *gm_n; int *gm_first; float *gm_first_af; float *gm_rest;
+};
+
+__device__ __forceinline__ AccPtrs acc_at(char *base, long long P, size_t o0, size_t o1, size_t o2, size_t o3,
+                                          size_t o4, size_t o5, size_t o6, size_t o7)
+{
+    AccPtrs a;
+    a.snt = (double *)(base + o0); a.srd = (long long *)(base + o1); a.cnt = (int *)(base + o2);
+    a.nrec = (int *)(base + o3); a.gm_n = (int *)(base + o4); a.gm_first = (int *)(base + o5);
+    a.gm_first_af = (float *)(base + o6); a.gm_rest = (float *)(base + o7);
+    return a;
+}
+
+__device__ __forceinline__ void lane_acc_store(const AccPtrs &t, long long P, long long p, const LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        t.snt[(0 * 4 + nt) * P + p] = a.snt[0][nt];
+        t.snt[(1 * 4 + nt) * P + p] = a.snt[1][nt];
+        t.srd[(0 * 4 + nt) * P + p] = a.srd[0][nt];
+        t.srd[(1 * 4 + nt) * P + p] = a.srd[1][nt];
+        t.cnt[nt * P + p] = a.cnt[nt];
+        t.gm_n[nt * P + p] = a.gm_n[nt];
+        t.gm_first[nt * P + p] = a.gm_first[nt];
+        t.gm_first_af[nt * P + p] = a.gm_first_af[nt];
+        t.gm_rest[nt * P + p] = a.gm_rest[nt];
+    }
+    t.nrec[p] = a.nrec;
+}
+
+__device__ __forceinline__ void lane_acc_load(const AccPtrs &t, long long P, long long p, LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        a.snt[0][nt] = t.snt[(0 * 4 + nt) * P + p];
+        a.snt[1][nt] = t.snt[(1 * 4 + nt) * P + p];
+        a.srd[0][nt] = t.srd[(0 * 4 + nt) * P + p];
+        a.srd[1][nt] = t.srd[(1 * 4 + nt) * P + p];
+        a.cnt[nt] = t.cnt[nt * P + p];
+        a.gm_n[nt] = t.gm_n[nt * P + p];
+        a.gm_first[nt] = t.gm_first[nt * P + p];
+        a.gm_first_af[nt] = t.gm_first_af[nt * P + p];
+        a.gm_rest[nt] = t.gm_rest[nt * P + p];
+    }
+    a.nrec = t.nrec[p];
+}
+
+// ---------------------------------------------------------------------------
+// error_reduce: workgroup = 4 waves x 64 positions.  Wave w of workgroup
+// (tile, split) owns the contiguous sample chunk c = split*4 + w and streams
+// its 64 positions' 32-byte records (2 KiB contiguous per sample row, two
+// dwordx4 per lane), UNROLL rows in flight.  The 4 per-wave partials are
+// combined in sample order through LDS; split > 1 leaves one partial table per
+// split for acc_merge_kernel.
+// ---------------------------------------------------------------------------
+constexpr int RED_WAVES = 4;
+constexpr int RED_UNROLL = 2;
+
+struct RedShared {
+    double snt[RED_WAVES - 1][8][64];
+    long long srd[RED_WAVES - 1][8][64];
+    int ints[RED_WAVES - 1][13][64];
+    float flts[RED_WAVES - 1][8][64];
+};
+
+__global__ __launch_bounds__(256) void error_reduce_kernel(
+    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
+    const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
+    const size_t part_stride, const size_t o0, const size_t o1, const size_t o2, const size_t o3, const size_t o4,
+    const size_t o5, const size_t o6, const size_t o7)
+{
+    __shared__ RedShared sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long p_raw = (long long)blockIdx.x * 64 + lane;
+    const bool valid = p_raw < P;
+    const long long p = valid ? p_raw : P - 1; // clamp: out-of-range lanes re-read the last position, never store
+    const long long R = P + E;
+    const int chunk = blockIdx.y * RED_WAVES + wave;
+    const int s0 = min(S, chunk * chunk_len);
+    const int s1 = min(S, s0 + chunk_len);
+
+    LaneAcc a;
+    lane_acc_init(a);
+
+    unsigned e0 = 0, e1 = 0;
+    if (E > 0) { e0 = dup_off[p]; e1 = dup_off[p + 1]; }
+    const bool any_dup = E > 0 && __any(e1 > e0);
+
+    int4 b0[RED_UNROLL], b1[RED_UNROLL];
+    // prologue: first batch
+#pragma unroll
+    for (int u = 0; u < RED_UNROLL; ++u) {
+        const int s = min(s0 + u, S - 1);
+        const int4 *q = recs + ((size_t)s * R + p) * 2;
+        b0[u] = q[0];
+        b1[u] = q[1];
+    }
+    for (int s = s0; s < s1; s += RED_UNROLL) {
+        int4 c0[RED_UNROLL], c1[RED_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) { c0[u] = b0[u]; c1[u] = b1[u]; }
+        // prefetch the next batch while this one is processed
+        if (s + RED_UNROLL < s1) {
+#pragma unroll
+            for (int u = 0; u < RED_UNROLL; ++u) {
+                const int sn = min(s + RED_UNROLL + u, S - 1);
+                const int4 *q = recs + ((size_t)sn * R + p) * 2;
+                b0[u] = q[0];
+                b1[u] = q[1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) {
+            if (s + u < s1) {
+                visit_record(a, c0[u], c1[u], first_sample + s + u, C, cov);
+                if (any_dup) { // extras of this position in the same sample, in file order
+                    for (unsigned e = e0; e < e1; ++e) {
+                        const int4 *q = recs + ((size_t)(s + u) * R + (size_t)P + e) * 2;
+                        visit_record(a, q[0], q[1], first_sample + s + u, C, cov);
+                    }
+                }
+            }
+        }
+    }
+
+    // ordered combine of the 4 wave partials through LDS (wave order = sample order)
+    if (wave > 0) {
+        const int w = wave - 1;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            sh.snt[w][nt][lane] = a.snt[0][nt]; sh.snt[w][4 + nt][lane] = a.snt[1][nt];
+            sh.srd[w][nt][lane] = a.srd[0][nt]; sh.srd[w][4 + nt][lane] = a.srd[1][nt];
+            sh.ints[w][nt][lane] = a.cnt[nt];
+            sh.ints[w][4 + nt][lane] = a.gm_n[nt];
+            sh.ints[w][8 + nt][lane] = a.gm_first[nt];
+            sh.flts[w][nt][lane] = a.gm_first_af[nt];
+            sh.flts[w][4 + nt][lane] = a.gm_rest[nt];
+        }
+        sh.ints[w][12][lane] = a.nrec;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll 1
+        for (int w = 0; w < RED_WAVES - 1; ++w) {
+            LaneAcc b;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                b.snt[0][nt] = sh.snt[w][nt][lane]; b.snt[1][nt] = sh.snt[w][4 + nt][lane];
+                b.srd[0][nt] = sh.srd[w][nt][lane]; b.srd[1][nt] = sh.srd[w][4 + nt][lane];
+                b.cnt[nt] = sh.ints[w][nt][lane];
+                b.gm_n[nt] = sh.ints[w][4 + nt][lane];
+                b.gm_first[nt] = sh.ints[w][8 + nt][lane];
+                b.gm_first_af[nt] = sh.flts[w][nt][lane];
+                b.gm_rest[nt] = sh.flts[w][4 + nt][lane];
+            }
+            b.nrec = sh.ints[w][12][lane];
+            lane_acc_merge(a, b);
+        }
+        if (valid) {
+            const AccPtrs t = acc_at(out_base + (size_t)blockIdx.y * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7);
+            lane_acc_store(t, P, p_raw, a);
+        }
+    }
+}
+
+// dst = parts[0] (+) parts[1] (+) ... in order; parts are tables at base + i*stride
+__global__ __launch_bounds__(256) void acc_merge_kernel(char *dst_base, const char *parts_base, const size_t part_stride,
+                                                        const int nparts, const long long P, const size_t o0,
+                                                        const size_t o1, const size_t o2, const size_t o3,
+                                                        const size_t o4, const size_t o5, const size_t o6,
+                                                        const size_t o7)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    LaneAcc a;
+    lane_acc_load(acc_at(const_cast<char *>(parts_base), P, o0, o1, o2, o3, o4, o5, o6, o7), P, p, a);
+    for (int i = 1; i < nparts; ++i) {
+        LaneAcc b;
+        lane_acc_load(acc_at(const_cast<char *>(parts_base) + (size_t)i * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7), P, p, b);
+        lane_acc_merge(a, b);
+    }
+    lane_acc_store(acc_at(dst_base, P, o0, o1, o2, o3, o4, o5, o6, o7), P, p, a);
+}
+
+// merge of arbitrary (non-strided) part tables: pointers passed through a small device array
+struct PartPtrs { AccPtrs t[1]; };
+
+__global__ __launch_bounds__(256) void acc_merge_ptr_kernel(AccPtrs dst, const AccPtrs *parts, const int nparts,
+                                                            const long long P)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    LaneAcc a;
+    lane_acc_load(parts[0], P, p, a);
+    for (int i = 1; i < nparts; ++i) {
+        LaneAcc b;
+        lane_acc_load(parts[i], P, p, b);
+        lane_acc_merge(a, b);
+    }
+    lane_acc_store(dst, P, p, a);
+}
+
+// germ-max triples only.  regions: nparts copies of the gm region of a table (gm_n .. end of gm_rest),
+// region k at regions + k*stride; plane offsets inside a region as in the table.
+__global__ __launch_bounds__(256) void gm_merge_kernel(int *gm_n, int *gm_first, float *gm_first_af, float *gm_rest,
+                                                       const char *regions, const size_t stride, const size_t of,
+                                                       const size_t ofa, const size_t orr, const int nparts,
+                                                       const long long P)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // over 4*P
+    if (i >= 4 * P) return;
+    int n = 0, first = 0x7fffffff;
+    float first_af = 0.0f, rest = -INFINITY;
+    for (int k = 0; k < nparts; ++k) {
+        const char *b = regions + (size_t)k * stride;
+        const int rn = ((const int *)b)[i];
+        if (rn == 0) continue;
+        const float fa = ((const float *)(b + ofa))[i], rr = ((const float *)(b + orr))[i];
+        if (n == 0) {
+            first = ((const int *)(b + of))[i]; first_af = fa; rest = rr;
+        } else {
+            if (rest <= fa) rest = fa;
+            if (rest <= rr) rest = rr;
+        }
+        n += rn;
+    }
+    gm_n[i] = n; gm_first[i] = first; gm_first_af[i] = first_af; gm_rest[i] = rest;
+}
+
+// ---------------------------------------------------------------------------
+// error_finalize
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void error_finalize_kernel(AccPtrs t, const long long P, const float C, const int cov,
+                                                             float *rate, unsigned char *code, float *thr,
+                                                             float *germ_val, unsigned char *germ_present, int *flags)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int nrec = t.nrec[p];
+    // exactness envelope of the double sums: every addend is a multiple of
+    // ulp(float(cov)*C) and the running sum must stay below 2^53 ulps.
+    const float pmin = (float)cov * C;
+    int ex;
+    (void)frexpf(pmin > 0 ? pmin : 1.0f, &ex);           // pmin = f * 2^ex, f in [0.5,1)
+    const double ulp = ldexp(1.0, ex - 24);              // lsb of an fp32 value of that magnitude
+    const double limit = ulp * 9007199254740992.0 * 0.5; // 2^52 ulps
+    bool bad = false;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const long long i = nt * P + p, ifw = (0 * 4 + nt) * P + p, ibw = (1 * 4 + nt) * P + p;
+        const int cnt = t.cnt[i];
+        const double sfw = t.snt[ifw], sbw = t.snt[ibw];
+        bad |= !(sfw < limit) || !(sbw < limit);
+        float r_fw = 0.0f, r_bw = 0.0f;
+        unsigned char c;
+        if ((double)cnt < 0.338 * (double)nrec) { // EE:1659
+            c = 1;
+        } else {
+            r_fw = (float)sfw / (float)(double)t.srd[ifw]; // EE:1679
+            r_bw = (float)sbw / (float)(double)t.srd[ibw]; // EE:1680
+            if (isnan(r_fw) || isnan(r_bw)) { c = 2; r_fw = 0.0f; r_bw = 0.0f; } // EE:1682
+            else c = 0;
+        }
+        code[i] = c;
+        rate[ifw] = r_fw;
+        rate[ibw] = r_bw;
+        if (thr) {
+            thr[ifw] = c ? 0.01f : ampli_text_roundtrip(r_fw); // EE:2680-2684 / EE:1704 -> VC:889-890
+            thr[ibw] = c ? 0.01f : ampli_text_roundtrip(r_bw);
+        }
+        if (germ_val) {
+            const int n = t.gm_n[i];
+            float v = (nt == 0) ? -888.0f : 0.0f; // EE:1260 / EE:1318,1374,1431
+            if (n > 1) { const float r = t.gm_rest[i]; if (v <= r) v = r; }
+            germ_val[i] = n ? v : 0.0f;
+            if (germ_present) germ_present[i] = n ? 1 : 0;
+        }
+    }
+    if (bad && flags) atomicOr(flags, 1);
+}
+
+// ---------------------------------------------------------------------------
+// poisson_call: one lane per record, SAMPLES_PER_BLOCK tumour samples per
+// workgroup so the position's 8 thresholds + reference code are loaded once
+// and reused from registers.
+// ---------------------------------------------------------------------------
+constexpr int PC_SAMPLES = 4;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void poisson_call_kernel(
+    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
+    const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
+    unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
+    unsigned long long *__restrict__ n_calls, double *__restrict__ qd, float *__restrict__ afd)
+{
+    const long long R = P + E;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long p = r < P ? r : (long long)ext_pos[r - P];
+    float th[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        th[0][nt] = thr[(0 * 4 + nt) * P + p]; // VC:887-890
+        th[1][nt] = thr[(1 * 4 + nt) * P + p];
+    }
+    const int ref = ref_code[p];
+    const int t0 = blockIdx.y * PC_SAMPLES;
+    for (int dt = 0; dt < PC_SAMPLES; ++dt) {
+        const int t = t0 + dt;
+        if (t >= T) break;
+        const size_t o = (size_t)t * R + r;
+        const int4 r0 = recs[o * 2], r1 = recs[o * 2 + 1];
+        const bool present = r0.x != AMPLI_ABSENT;
+        const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
+        const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
+        const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
+        const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
+        const int RD = FW + BW;
+        const bool covok = FW >= cov && BW >= cov;    // VC:898
+        unsigned mask = 0;
+        if (qd) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qd[o * 8 + j] = -1.0;
+        }
+        if (afd) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { // VC:772-817
+                afd[o * 12 + nt * 3 + 0] = present ? (float)(fw[nt] + bw[nt]) / (float)RD : 0.0f;
+                afd[o * 12 + nt * 3 + 1] = (present && FW != 0) ? (float)fw[nt] / (float)FW : 0.0f;
+                afd[o * 12 + nt * 3 + 2] = (present && BW != 0) ? (float)bw[nt] / (float)BW : 0.0f;
+            }
+        }
+        if (present && ref <= 3) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (nt == ref) continue;
+                // VC:895-896: forward depth is RD - RD_reverse
+                const int k_fw = fw[nt], d_fw = RD - BW, k_bw = bw[nt], d_bw = BW;
+                double q_fw, q_bw;
+                if (MODE == AMPLI_POISSON_PREFILTER) {
+                    if (!covok) continue;
+                    if (ampli_prefilter_nocall(k_fw, d_fw, th[0][nt]) || ampli_prefilter_nocall(k_bw, d_bw, th[1][nt])) continue;
+                    q_fw = ampli_poisson_score(k_fw, d_fw, th[0][nt]);
+                    if (!(q_fw >= 5)) continue;
+                    q_bw = ampli_poisson_score(k_bw, d_bw, th[1][nt]);
+                } else {
+                    q_fw = ampli_poisson_score(k_fw, d_fw, th[0][nt]);
+                    q_bw = ampli_poisson_score(k_bw, d_bw, th[1][nt]);
+                    if (qd) { qd[o * 8 + nt * 2 + 0] = q_fw; qd[o * 8 + nt * 2 + 1] = q_bw; }
+                }
+                if (covok && q_fw >= 5 && q_bw >= 5) { // VC:898
+                    mask |= 1u << nt;
+                    if (n_calls) {
+                        const unsigned long long idx = atomicAdd(n_calls, 1ull);
+                        if (calls && (long long)idx < capacity) {
+                            ampli_call c;
+                            c.sample = t; c.record = (int)r; c.alt = nt; c.pad = 0;
+                            c.q_fw = q_fw; c.q_bw = q_bw;
+                            c.af = (float)(fw[nt] + bw[nt]) / (float)RD;          // VC:814-817
+                            c.af_fw = FW == 0 ? 0.0f : (float)fw[nt] / (float)FW; // VC:785-790
+                            c.af_bw = BW == 0 ? 0.0f : (float)bw[nt] / (float)BW; // VC:805-810
+                            c.pad2 = 0.0f;
+                            calls[idx] = c;
+                        }
+                    }
+                }
+            }
+        }
+        call_mask[o] = (unsigned char)mask;
+    }
+}
+
+__global__ void score_batch_kernel(const int *k, const int *rd, const float *err, const long long n, double *q, double *pv)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (q) q[i] = ampli_poisson_score(k[i], rd[i], err[i]);
+    if (pv) pv[i] = err[i] == -1 ? -1.0 : ampli_poisson_p(k[i], rd[i], err[i]);
+}
+
+__global__ void roundtrip_batch_kernel(const float *in, const long long n, float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ampli_text_roundtrip(in[i]);
+}
+
+__global__ void synth_fill_kernel(int4 *recs, const long long P, const int n_samples, const int first_sample,
+                                  const unsigned long long seed, const int depth, const int tumour)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.y;
+    if (p >= P || s >= n_samples) return;
+    int rec[8];
+    ampli_synth_record(seed, (uint64_t)p, (uint64_t)(first_sample + s), depth, tumour, rec);
+    const size_t o = ((size_t)s * P + p) * 2;
+    recs[o] = make_int4(rec[0], rec[1], rec[2], rec[3]);
+    recs[o + 1] = make_int4(rec[4], rec[5], rec[6], rec[7]);
+}
+
+__global__ void synth_ref_kernel(unsigned char *ref, const long long P, const unsigned long long seed)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) ref[p] = (unsigned char)ampli_synth_ref_base(seed, (uint64_t)p);
+}
+
+// ---------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------
+static int check_launch(ampli_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        return AMPLI_E_HIP;
+    }
+    return AMPLI_OK;
+}
+
+static int ensure_ws(ampli_ctx *ctx, size_t bytes)
+{
+    if (ctx->ws_bytes >= bytes) return AMPLI_OK;
+    if (ctx->ws) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    if (hipMalloc(&ctx->ws, bytes) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "workspace hipMalloc failed");
+    ctx->ws_bytes = bytes;
+    return AMPLI_OK;
+}
+
+// a bound table must be one buffer carved by ampli_acc_bind
+static bool acc_is_bound(const ampli_acc_table *t)
+{
+    if (!t || !t->snt || t->P <= 0) return false;
+    size_t off[9];
+    acc_offsets(t->P, off);
+    const char *b = (const char *)t->snt;
+    return (const char *)t->srd == b + off[1] && (const char *)t->cnt == b + off[2] && (const char *)t->nrec == b + off[3] &&
+           (const char *)t->gm_n == b + off[4] && (const char *)t->gm_first == b + off[5] &&
+           (const char *)t->gm_first_af == b + off[6] && (const char *)t->gm_rest == b + off[7];
+}
+
+static AccPtrs to_ptrs(const ampli_acc_table *t)
+{
+    AccPtrs a;
+    a.snt = t->snt; a.srd = (long long *)t->srd; a.cnt = t->cnt; a.nrec = t->nrec; a.gm_n = t->gm_n;
+    a.gm_first = t->gm_first; a.gm_first_af = t->gm_first_af; a.gm_rest = t->gm_rest;
+    return a;
+}
+
+extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                                  int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || !acc_is_bound(d_acc) || d_acc->P != P)
+        return fail(ctx, AMPLI_E_INVALID, "error_reduce: bad argument (P,S>0, cov>=1, table bound with ampli_acc_bind for the same P)");
+    if (E > 0 && !d_dup_off) return fail(ctx, AMPLI_E_INVALID, "error_reduce: E > 0 needs dup_off");
+    if (((uintptr_t)d_recs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+    const long long tiles = (P + 63) / 64;
+    // sample splits: enough waves to fill the chip (>= ~16 waves per CU), each with >= 8 samples
+    int splits = ctx->reduce_splits;
+    if (splits <= 0) {
+        const long long want_waves = (long long)ctx->n_cu * 24;
+        splits = (int)((want_waves + tiles * RED_WAVES - 1) / (tiles * RED_WAVES));
+        const int max_splits = (S + RED_WAVES * 8 - 1) / (RED_WAVES * 8);
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    if (splits > S) splits = S;
+    const int chunks = splits * RED_WAVES;
+    const int chunk_len = (S + chunks - 1) / chunks;
+
+    size_t off[9];
+    acc_offsets(P, off);
+    char *out_base = (char *)d_acc->snt;
+    size_t stride = 0;
+    if (splits > 1) {
+        int rc = ensure_ws(ctx, off[8] * (size_t)splits);
+        if (rc) return rc;
+        out_base = (char *)ctx->ws;
+        stride = off[8];
+    }
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    hipLaunchKernelGGL(error_reduce_kernel, grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, (long long)E,
+                       d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0], off[1], off[2],
+                       off[3], off[4], off[5], off[6], off[7]);
+    int rc = check_launch(ctx, "error_reduce_kernel");
+    if (rc) return rc;
+    if (splits > 1) {
+        hipLaunchKernelGGL(acc_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, (char *)d_acc->snt,
+                           (const char *)ctx->ws, stride, splits, (long long)P, off[0], off[1], off[2], off[3], off[4], off[5],
+                           off[6], off[7]);
+        rc = check_launch(ctx, "acc_merge_kernel");
+    }
+    return rc;
+}
+
+extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_acc_table *d_parts, int32_t nparts)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_dst || !d_parts || nparts < 1 || nparts > 64) return fail(ctx, AMPLI_E_INVALID, "acc_merge: 1 <= nparts <= 64");
+    const int64_t P = d_dst->P;
+    for (int i = 0; i < nparts; ++i)
+        if (d_parts[i].P != P) return fail(ctx, AMPLI_E_INVALID, "acc_merge: part table P mismatch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_ws(ctx, sizeof(AccPtrs) * 64);
+    if (rc) return rc;
+    AccPtrs hp[64];
+    for (int i = 0; i < nparts; ++i) hp[i] = to_ptrs(&d_parts[i]);
+    // small synchronous upload of the pointer list (not on a captured path)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, hp, sizeof(AccPtrs) * nparts, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL(acc_merge_ptr_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_dst),
+                       (const AccPtrs *)ctx->ws, (int)nparts, (long long)P);
+    return check_launch(ctx, "acc_merge_ptr_kernel");
+}
+
+extern "C" int ampli_acc_regions(int64_t P, size_t *sum_bytes, size_t *gm_offset, size_t *gm_bytes)
+{
+    if (P <= 0) return AMPLI_E_INVALID;
+    size_t off[9];
+    acc_offsets(P, off);
+    if (sum_bytes) *sum_bytes = off[5]; // snt|srd|cnt|nrec|gm_n
+    if (gm_offset) *gm_offset = off[4];
+    if (gm_bytes) *gm_bytes = off[8] - off[4];
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_gm_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const void *d_regions, int32_t nparts)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_dst || !d_regions || nparts < 1) return fail(ctx, AMPLI_E_INVALID, "gm_merge: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long P = d_dst->P;
+    size_t off[9];
+    acc_offsets(P, off);
+    hipLaunchKernelGGL(gm_merge_kernel, dim3((unsigned)((4 * P + 255) / 256)), dim3(256), 0, ctx->stream, d_dst->gm_n,
+                       d_dst->gm_first, d_dst->gm_first_af, d_dst->gm_rest, (const char *)d_regions, off[8] - off[4],
+                       off[5] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, P);
+    return check_launch(ctx, "gm_merge_kernel");
+}
+
+extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc, float C, int32_t cov, float *d_rate,
+                                    uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present,
+                                    int32_t *d_flags)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_acc || d_acc->P <= 0 || !d_rate || !d_code || cov < 1) return fail(ctx, AMPLI_E_INVALID, "error_finalize: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long P = d_acc->P;
+    hipLaunchKernelGGL(error_finalize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P,
+                       C, (int)cov, d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags);
+    return check_launch(ctx, "error_finalize_kernel");
+}
+
+extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
+                                  int32_t T, const float *d_thr, const uint8_t *d_ref_code, int32_t cov, int32_t mode,
+                                  uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+                                  unsigned long long *d_n_calls, double *d_q, float *d_af)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_trecs || P <= 0 || E < 0 || T <= 0 || !d_thr || !d_ref_code || !d_call_mask || cov < 1)
+        return fail(ctx, AMPLI_E_INVALID, "poisson_call: bad argument");
+    if (E > 0 && !d_ext_pos) return fail(ctx, AMPLI_E_INVALID, "poisson_call: E > 0 needs ext_pos");
+    if (mode != AMPLI_POISSON_FULL && mode != AMPLI_POISSON_PREFILTER) return fail(ctx, AMPLI_E_INVALID, "poisson_call: bad mode");
+    if (d_q && mode != AMPLI_POISSON_FULL) return fail(ctx, AMPLI_E_INVALID, "poisson_call: dense q needs AMPLI_POISSON_FULL");
+    if (d_calls && (!d_n_calls || capacity <= 0)) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call list needs n_calls and capacity");
+    if (((uintptr_t)d_trecs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long R = P + E;
+    dim3 grid((unsigned)((R + 255) / 256), (unsigned)((T + PC_SAMPLES - 1) / PC_SAMPLES));
+    if (mode == AMPLI_POISSON_FULL)
+        hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_FULL>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
+                           (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
+                           (long long)capacity, d_n_calls, d_q, d_af);
+    else
+        hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_PREFILTER>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
+                           (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
+                           (long long)capacity, d_n_calls, d_q, d_af);
+    return check_launch(ctx, "poisson_call_kernel");
+}
+
+extern "C" int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err, int64_t n,
+                                 double *d_q, double *d_p)
+{
+    if (!ctx || !d_k || !d_rd || !d_err || n <= 0) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(score_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_rd, d_err,
+                       (long long)n, d_q, d_p);
+    return check_launch(ctx, "score_batch_kernel");
+}
+
+extern "C" int ampli_roundtrip_batch(ampli_ctx *ctx, const float *d_in, int64_t n, float *d_out)
+{
+    if (!ctx || !d_in || !d_out || n <= 0) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(roundtrip_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, (long long)n, d_out);
+    return check_launch(ctx, "roundtrip_batch_kernel");
+}
+
+extern "C" int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int32_t n_samples, int32_t first_sample,
+                                uint64_t seed, int32_t depth, int32_t tumour)
+{
+    if (!ctx || !d_recs || P <= 0 || n_samples <= 0 || depth <= 0) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)n_samples), dim3(256), 0, ctx->stream,
+                       (int4 *)d_recs, (long long)P, (int)n_samples, (int)first_sample, (unsigned long long)seed, (int)depth, (int)tumour);
+    return check_launch(ctx, "synth_fill_kernel");
+}
+
+extern "C" int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t seed)
+{
+    if (!ctx || !d_ref_code || P <= 0) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_code, (long long)P,
+                       (unsigned long long)seed);
+    return check_launch(ctx, "synth_ref_kernel");
+}

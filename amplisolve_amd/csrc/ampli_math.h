@@ -1,0 +1,183 @@
+// amplisolve_amd/csrc/ampli_math.h
+//
+// Scalar arithmetic of the hot path, shared by the HIP kernels (device) and by
+// the C++ host (formatting / CPU-side unit checks of the same code).  Each
+// function names the reference lines whose result it must reproduce:
+//   EE:n = source_codes/AmpliSolveErrorEstimation.cpp:n, VC:n = source_codes/AmpliSolveVariantCalling.cpp:n
+#ifndef AMPLI_MATH_H
+#define AMPLI_MATH_H
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define AMPLI_FN __host__ __device__ __forceinline__
+#else
+#define AMPLI_FN static inline
+#endif
+
+// ---------------------------------------------------------------------------
+// AF gate.  The reference computes af = float(x)/float(d), widens it to double
+// and tests af <= 0.05 (EE:1229,1251 and EE:1592-1595).  0.05 (double) lies
+// strictly between the adjacent floats f0 = 13421772*2^-28 and f1 = f0 + 2^-28,
+// so the test is RN(x/d) <= f0.  With round-to-nearest-even and f0's even
+// significand that is x/d <= (f0+f1)/2 = 26843545 * 2^-29, i.e. for exactly
+// representable x, d (< 2^24):   x <= floor(d * 26843545 / 2^29).
+// One 64-bit multiply per (record, strand) instead of one IEEE division per
+// (record, strand, nucleotide).  d == 0 gives limit 0; callers AND the gate
+// with d >= coverage_cutoff >= 1 as the reference does, which also removes
+// the 0/0 = NaN case.
+// ---------------------------------------------------------------------------
+#define AMPLI_AF_MID_NUM 26843545ull
+#define AMPLI_AF_MID_SHIFT 29
+#define AMPLI_COUNT_LIMIT (1 << 24)
+
+AMPLI_FN int32_t ampli_af_limit(int32_t d)
+{
+    return (int32_t)(((uint64_t)(uint32_t)d * AMPLI_AF_MID_NUM) >> AMPLI_AF_MID_SHIFT);
+}
+
+// literal form, for operands outside the exact-float range and for tests
+AMPLI_FN int ampli_af_gate_fp(int32_t x, int32_t d)
+{
+    double af = (double)((float)x / (float)d);
+    return af <= 0.05;
+}
+
+// ---------------------------------------------------------------------------
+// stof(sprintf("%f", r)): the rate as AmpliSolveVariantCalling reads it back
+// from the error table (EE:1704 -> VC:887-890), in exact integer arithmetic.
+//   "%f" prints round-half-even(r * 10^6) / 10^6 (glibc rounds the exact binary
+//   value); r = m * 2^e with m < 2^24, so m * 10^6 < 2^44 fits an int64.
+//   For r >= 16 the float spacing (>= 2^-19) exceeds 2 * 5e-7, so the nearest
+//   float to the printed decimal is r itself.  Below 16, N < 2^24 and 10^6 are
+//   both exact floats and the correctly rounded fp32 quotient N / 10^6 is the
+//   float nearest to the printed decimal, which is what strtof returns.
+// ---------------------------------------------------------------------------
+AMPLI_FN float ampli_text_roundtrip(float r)
+{
+    uint32_t bits;
+    memcpy(&bits, &r, 4);
+    const uint32_t sign = bits & 0x80000000u;
+    const uint32_t ex = (bits >> 23) & 0xFF;
+    uint32_t man = bits & 0x7FFFFFu;
+    if (ex == 0xFF) return r; // inf / nan: not produced by the reference's finalize (NaN is caught before)
+    float a = fabsf(r);
+    if (a >= 16.0f) return r;
+    int e2;
+    if (ex == 0) {
+        e2 = -149;
+    } else {
+        man |= 0x800000u;
+        e2 = (int)ex - 150;
+    }
+    // a = man * 2^e2, e2 <= -20 here
+    const uint64_t A = (uint64_t)man * 1000000ull;
+    const int k = -e2;
+    uint64_t N;
+    if (k >= 45) {
+        N = 0; // A < 2^44 <= 2^(k-1): rounds to 0
+    } else {
+        const uint64_t q = A >> k, rem = A & ((1ull << k) - 1), half = 1ull << (k - 1);
+        N = q + ((rem > half) || (rem == half && (q & 1)));
+    }
+    float out = (float)(uint32_t)N / 1000000.0f;
+    uint32_t ob;
+    memcpy(&ob, &out, 4);
+    ob |= sign; // "-0.000000" parses to -0.0f
+    memcpy(&out, &ob, 4);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// Poisson scorer: kf_lgamma / _kf_gammap / _kf_gammaq / kf_gammaq as adopted by
+// the reference from samtools kfunc.c (VC:3721-3830), including the 99-step
+// caps, KF_GAMMA_EPS 1e-14 and KF_TINY 1e-290 (VC:149-150).
+// ---------------------------------------------------------------------------
+AMPLI_FN double ampli_kf_lgamma(double z)
+{
+    double x = 0;
+    x += 0.1659470187408462e-06 / (z + 7);
+    x += 0.9934937113930748e-05 / (z + 6);
+    x -= 0.1385710331296526 / (z + 5);
+    x += 12.50734324009056 / (z + 4);
+    x -= 176.6150291498386 / (z + 3);
+    x += 771.3234287757674 / (z + 2);
+    x -= 1259.139216722289 / (z + 1);
+    x += 676.5203681218835 / z;
+    x += 0.9999999999995183;
+    return log(x) - 5.58106146679532777 - z + (z - 0.5) * log(z + 6.5);
+}
+
+AMPLI_FN double ampli_kf_gammap_series(double s, double z)
+{
+    double sum = 1., x = 1.;
+    for (int k = 1; k < 100; ++k) {
+        x *= z / (s + k);
+        sum += x;
+        if (x / sum < 1e-14) break;
+    }
+    return exp(s * log(z) - z - ampli_kf_lgamma(s + 1.) + log(sum));
+}
+
+AMPLI_FN double ampli_kf_gammaq_cf(double s, double z)
+{
+    double f = 1. + z - s, C = f, D = 0.;
+    for (int j = 1; j < 100; ++j) {
+        const double a = j * (s - j), b = (j << 1) + 1 + z - s;
+        D = b + a * D;
+        if (D < 1e-290) D = 1e-290;
+        C = b + a / C;
+        if (C < 1e-290) C = 1e-290;
+        D = 1. / D;
+        const double d = C * D;
+        f *= d;
+        if (fabs(d - 1.) < 1e-14) break;
+    }
+    return exp(s * log(z) - z - ampli_kf_lgamma(s) - log(f));
+}
+
+AMPLI_FN double ampli_kf_gammaq(double s, double z)
+{
+    return (z <= 1. || z < s) ? 1. - ampli_kf_gammap_series(s, z) : ampli_kf_gammaq_cf(s, z);
+}
+
+// p as formed at VC:3858-3865 (before the clamp); err already != -1
+AMPLI_FN double ampli_poisson_p(int32_t k, int32_t rd, float err)
+{
+    if (err == 0) err = 0.0010008f; // VC:3852-3856 (double literal narrowed to float)
+    if (k == 0) return 1.0;         // VC:3858-3861
+    const double m = (double)rd * err; // VC:3864: double * float
+    return 1 - ampli_kf_gammaq((double)k, m);
+}
+
+// Q = -10 log10 p with the reference's clamps (VC:3844-3880).  The reference
+// takes the final log10 in long double; fp64 differs by < 1e-14 relative.
+AMPLI_FN double ampli_q_from_p(double p)
+{
+    if (p < 0.0000000001) return 100.0; // -10*log10l(1e-10), (double) of which is 100
+    if (p == 1) return 0.0;
+    return -10 * log10(p);
+}
+
+AMPLI_FN double ampli_poisson_score(int32_t k, int32_t rd, float err)
+{
+    if (err == -1) return -888.0; // VC:3844-3849
+    return ampli_q_from_p(ampli_poisson_p(k, rd, err));
+}
+
+// Exact-decision bound used by AMPLI_POISSON_PREFILTER: when k <= m the
+// reference's own scorer returns Q < 5 (P(X >= k) > 0.31 for k <= mean; checked
+// exhaustively against the scorer incl. its iteration caps in
+// tests/test_prefilter.py), so VC:898 is false whatever the other strand says.
+// err == -1 gives Q = -888 < 5 as well.
+AMPLI_FN int ampli_prefilter_nocall(int32_t k, int32_t rd, float err)
+{
+    if (err == -1) return 1;
+    if (err == 0) err = 0.0010008f;
+    if (k == 0) return 1;
+    const double m = (double)rd * err;
+    return (double)k <= m;
+}
+
+#endif

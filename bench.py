@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- AmpliSolve hot path on MI355X: error estimation + Poisson calling.
+
+One "step" = one pass of the hot path over one synthetic batch that is already
+resident in HBM: error_reduce over the rank's normal-sample shard -> (N>1: RCCL
+merge of the accumulator table) -> error_finalize -> poisson_call over the
+rank's tumour shard.  Workload at N=1: BASELINE.json configs[2], the one the
+metric's target is quoted on (100k positions x 256 normals x 96 tumours);
+weak scaling: every rank owns a shard of that size.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt).  `value` counts
+position-evaluations: one (position, sample) record pushed through its half of
+the path (normals through the gated reduction, tumours through the Poisson
+test), whole job, per second.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+SEED = 0xA3F15017 + 2   # seed base + config index
+
+CONFIGS = {
+    "c2": dict(P=10_000, S=32, T=8, depth=2000, name="synthetic 10k positions x 32 normals x 8 tumours"),
+    "c3": dict(P=100_000, S=256, T=96, depth=2000, name="synthetic 100k positions x 256 normals x 96 tumours (ctDNA-scale)"),
+    "c4r": dict(P=100_000, S=128, T=128, depth=2000, name="synthetic 100k x 1024 normals x 1024 tumours, per-rank shard of 8"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="prefilter", choices=["prefilter", "full"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--splits", type=int, default=0, help="error_reduce sample splits (0 = auto)")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------------------------------
+# CPU baseline leg (rank 0, N=1): the reference's own error-estimation code when oracle/_ref holds it,
+# and the oracle port for both halves.  Bounded sample of the same synthetic workload.
+# ----------------------------------------------------------------------------------------------------
+def _write_aseq_dir(recs, chrom_pos, d):
+    """recs [S][P][8] numpy -> S .PILEUP.ASEQ files (columns as EE:1149)."""
+    import numpy as np
+
+    os.makedirs(d, exist_ok=True)
+    S, P, _ = recs.shape
+    chroms = np.array([c for c, _ in chrom_pos])
+    poss = np.array([p for _, p in chrom_pos])
+    for s in range(S):
+        r = recs[s]
+        present = r[:, 0] != np.iinfo(np.int32).min
+        fw, bw = r[:, :4].astype(np.int64), r[:, 4:].astype(np.int64)
+        tot = fw + bw
+        rd = tot.sum(1)
+        with open(os.path.join(d, f"N{s:04d}.PILEUP.ASEQ"), "w") as f:
+            f.write("chr\tpos\tdbsnp\tMAF\tref\talt\tA\tC\tG\tT\tRD\tArs\tCrs\tGrs\tTrs\n")
+            lines = [f"{chroms[p]}\t{poss[p]}\t.\t.\t.\t.\t{tot[p,0]}\t{tot[p,1]}\t{tot[p,2]}\t{tot[p,3]}\t{rd[p]}\t"
+                     f"{bw[p,0]}\t{bw[p,1]}\t{bw[p,2]}\t{bw[p,3]}\n" for p in range(P) if present[p]]
+            f.write("".join(lines))
+
+
+def synthetic_panel(P, n_regions=30):
+    """30 amplicon regions on chr1..22,X cycling, ceil(P/30) consecutive 1-based positions each."""
+    chroms = [f"chr{i}" for i in range(1, 23)] + ["chrX"]
+    per = -(-P // n_regions)
+    rows, pos = [], []
+    for i in range(n_regions):
+        n = min(per, P - i * per)
+        if n <= 0:
+            break
+        c = chroms[i % len(chroms)]
+        start = 1_000_000 + (i // len(chroms)) * 5_000_000
+        rows.append((c, start, start + n - 1))
+        pos += [(c, start + j) for j in range(n)]
+    return rows, pos
+
+
+def cpu_baseline(cfg):
+    import numpy as np
+
+    from oracle import pyoracle as orc
+    from tests.helpers import synth_recs, synth_ref
+
+    out = {}
+    # --- port (oracle) on both halves -----------------------------------------------------------
+    P, S, T = 20_000, 64, 24
+    normals = synth_recs(P, S, seed=SEED, depth=cfg["depth"])
+    tumours = synth_recs(P, T, seed=SEED, depth=cfg["depth"], tumour=True)
+    ref = synth_ref(P, seed=SEED)
+    t0 = time.perf_counter()
+    acc = orc.error_reduce(normals, P, 0.002, 100)
+    fin = orc.error_finalize(acc)
+    t1 = time.perf_counter()
+    orc.poisson_call(tumours, P, fin["thr"], ref, 100, dense=False)
+    t2 = time.perf_counter()
+    port = dict(value=(P * S + P * T) / (t2 - t0), unit="position-evaluations/s", cores=1, kind="port",
+                sample=f"oracle/ampli_oracle.c on {P} positions x {S} normals + {T} tumours of the same synthetic panel "
+                       f"(error-est {t1 - t0:.3f} s, calling {t2 - t1:.3f} s)")
+    out = port
+    # --- the reference's own code for the error-estimation half --------------------------------
+    drv = orc.REF_EE_DRIVER
+    if os.path.exists(drv):
+        Pr, Sr = 10_000, 24
+        rows, pos = synthetic_panel(Pr)
+        recs = synth_recs(Pr, Sr, seed=SEED, depth=cfg["depth"])
+        refb = synth_ref(Pr, seed=SEED)
+        with tempfile.TemporaryDirectory(prefix="ampli_ref_") as d:
+            _write_aseq_dir(recs, pos, os.path.join(d, "normals"))
+            with open(os.path.join(d, "panel.bed"), "w") as f:
+                f.write("".join(f"{c}\t{a}\t{b}\tAMPL{i}\trs{i}\tGENE{i}\n" for i, (c, a, b) in enumerate(rows)))
+            with open(os.path.join(d, "refbases.txt"), "w") as f:
+                f.write("".join(f"{c}\t{p}\t{'ACGT'[refb[i]]}\n" for i, (c, p) in enumerate(pos)))
+            open(os.path.join(d, "dups.txt"), "w").close()
+            os.makedirs(os.path.join(d, "out"))
+            r = subprocess.run([drv, os.path.join(d, "panel.bed"), os.path.join(d, "refbases.txt"), os.path.join(d, "dups.txt"),
+                                os.path.join(d, "normals"), "0.002", "100", os.path.join(d, "out")],
+                               capture_output=True, text=True, cwd=d)
+            tm = {ln.split()[1]: float(ln.split()[2]) for ln in r.stderr.splitlines() if ln.startswith("TIMING")}
+        if r.returncode == 0 and "storeGermlineStatistics" in tm:
+            t_ref = tm["storeGermlineStatistics"] + tm["estimateThresholds"] + tm["generateFinalOutput"]
+            out = dict(value=tm["records"] / t_ref, unit="position-evaluations/s", cores=1, kind="reference",
+                       sample=f"reference AmpliSolveErrorEstimation.cpp compiled -O2 from /root/reference (oracle/_ref/ee_ref_driver: "
+                              f"storeGermlineStatistics+estimateThresholds+generateFinalOutput, samtools step excluded) on "
+                              f"{Pr} positions x {Sr} normals of the same synthetic panel = {int(tm['records'])} records in {t_ref:.2f} s; "
+                              f"error-estimation half only: the calling half of the reference needs Boost (unbuildable here), "
+                              f"see 'port' for the oracle on both halves",
+                       port=port)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    cfg = CONFIGS[args.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    from amplisolve_amd import Context
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+    from amplisolve_amd.dist import merge_error_table
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = Context(local_rank)
+    if args.splits:
+        ctx.set_tuning(args.splits)
+    mode = POISSON_PREFILTER if args.mode == "prefilter" else POISSON_FULL
+
+    P, S, T, depth = cfg["P"], cfg["S"], cfg["T"], cfg["depth"]
+    # synthetic shard of this rank, generated in HBM (bit-identical to the host generator)
+    normals = ctx.synth_fill(P, S, first_sample=rank * S, seed=SEED, depth=depth)
+    tumours = ctx.synth_fill(P, T, first_sample=rank * T, seed=SEED, depth=depth, tumour=True)
+    ref_code = ctx.synth_ref(P, seed=SEED)
+    acc = ctx.new_acc(P)
+    acc.buf.zero_()
+    fin = None
+    call_mask = torch.empty((T, P), dtype=torch.uint8, device=ctx.device)
+    cap = 1 << 20
+    from amplisolve_amd._lib import Call
+    import ctypes
+
+    calls_buf = torch.empty((cap * ctypes.sizeof(Call),), dtype=torch.uint8, device=ctx.device)
+    n_calls = torch.zeros((1,), dtype=torch.int64, device=ctx.device)
+    gather_buf = None
+    if world > 1:
+        _, _, gm_bytes = ctx.regions(P)
+        gather_buf = torch.empty(world * gm_bytes, dtype=torch.uint8, device=ctx.device)
+
+    ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
+
+    def step(i=None):
+        nonlocal fin
+        if i is not None:
+            ctx.record(ev[i][0])
+        ctx.error_reduce(normals, P, 0.002, 100, first_sample=rank * S, acc=acc)
+        if i is not None:
+            ctx.record(ev[i][1])
+        if world > 1:
+            merge_error_table(ctx, acc, gather_buf=gather_buf)
+        fin = ctx.error_finalize(acc, 0.002, 100, out=fin)
+        n_calls.zero_()
+        if i is not None:
+            ctx.record(ev[i][2])
+        ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
+                         calls_buf=calls_buf, n_calls=n_calls)
+        if i is not None:
+            ctx.record(ev[i][3])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    t_red = sum(ctx.elapsed_ms(e[0], e[1]) for e in ev) / args.steps
+    t_call = sum(ctx.elapsed_ms(e[2], e[3]) for e in ev) / args.steps
+    n_found = int(n_calls.item())
+    flags = int(fin.flags.item())
+    if flags != 0:
+        raise SystemExit("error_finalize reported an exactness-envelope violation")
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        evals = world * (P * S + P * T) * args.steps
+        acc_bytes = ctx.lib.ampli_acc_bytes(P)
+        red_bytes = 32 * P * S + acc_bytes                 # algorithmic bytes of error_reduce per launch
+        call_bytes = 32 * P * T + 33 * P + P * T           # poisson_call: records + thresholds/ref + mask
+        if t_red >= t_call:
+            dom, dom_ms, dom_bytes = "error_reduce_kernel", t_red, red_bytes
+        else:
+            dom, dom_ms, dom_bytes = "poisson_call_kernel", t_call, call_bytes
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "position-evaluations/s (error-est + Poisson call)",
+            "value": evals / elapsed,
+            "unit": "position-evaluations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32 counts; f64 sums / Poisson; f32 rates",
+            "data": "synthetic",
+            "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "depth": depth,
+                       "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode,
+                       "parallelism": f"tumour+normal sample shards x{world}" + ("; RCCL all-reduce + all-gather of the error table" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes},
+            "kernels": {"error_reduce_ms": t_red, "error_reduce_GBs": red_bytes / (t_red * 1e-3) / 1e9,
+                        "poisson_call_ms": t_call, "poisson_call_GBs": call_bytes / (t_call * 1e-3) / 1e9,
+                        "R_EE_positions_per_s": P / (t_red * 1e-3), "R_VC_evals_per_s": P * T / (t_call * 1e-3)},
+            "calls_per_step": n_found,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+            except Exception as e:  # the baseline leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "position-evaluations/s", "cores": 1, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,222 @@
+/*
+ * include/amplisolve_hip.h -- C ABI of libamplisolve_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of AmpliSolve is its two command lines and their files
+ * (SURVEY.md section 8b); the reference exposes no library interface.  This
+ * header is the thin C ABI between the C++ host that re-states those command
+ * lines (amplisolve_amd/csrc/host) and the hand-written HIP kernels that do the
+ * per-position arithmetic.  Every entry point names the reference code it
+ * replaces:
+ *   EE:n = /root/reference/source_codes/AmpliSolveErrorEstimation.cpp:n
+ *   VC:n = /root/reference/source_codes/AmpliSolveVariantCalling.cpp:n
+ *
+ * Conventions: C linkage, plain pointers and sizes, no exceptions across the
+ * boundary.  Every call returns AMPLI_OK (0) or a negative AMPLI_E_* code;
+ * ampli_last_error(ctx) gives the detail text.  A context is bound to one
+ * device and one HIP stream; all work is enqueued on that stream and is
+ * asynchronous unless stated.  The caller owns every buffer.  Pointers named
+ * d_* are DEVICE pointers (hipMalloc / ampli_dev_alloc / a torch CUDA tensor).
+ * There is no CPU fallback: without a GPU every compute entry point fails
+ * with AMPLI_E_HIP.
+ *
+ * Record arrays (the "count SoA"):
+ *   int32 recs[n_samples][R][8],  R = P + E, position index fastest-but-one,
+ *   one 32-byte vector {Afw,Cfw,Gfw,Tfw,Ars,Crs,Grs,Trs} per (sample, record):
+ *   a dense (position x strand x base) tensor per sample.  Xfw = X - Xrs
+ *   (EE:1155-1158, VC:767-770), Xrs = the ASEQ reverse-strand column.
+ *   Absent record (the sample's file has no line for the position):
+ *   recs[..][0] == AMPLI_ABSENT.
+ *   P = unique panel positions.  Record r < P is the first line of position r
+ *   in the sample's file.  E = extra occurrences: a position covered by
+ *   overlapping amplicons is listed again in every ASEQ file and each line is
+ *   a record of its own (it counts in the quorum, the sums and the germ-max
+ *   sequence).  Extras of position p are records P+dup_off[p] ..
+ *   P+dup_off[p+1]-1 and are visited right after record (s,p) (file order);
+ *   ext_pos[e] is the position of extra e.  E = 0: pass NULL for both.
+ *   Samples are in the reference's visit order (EE:1081 / VC:672).
+ *   Counts must be < 2^24 (AMPLI_E_RANGE is reported by the host packer).
+ */
+#ifndef AMPLISOLVE_HIP_H
+#define AMPLISOLVE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMPLI_ABI_VERSION 1
+#define AMPLI_ABSENT INT32_MIN
+
+#define AMPLI_OK 0
+#define AMPLI_E_INVALID (-1)  /* bad argument */
+#define AMPLI_E_HIP (-2)      /* HIP runtime error / no device */
+#define AMPLI_E_NOMEM (-3)
+#define AMPLI_E_ENVELOPE (-4) /* double accumulators left the exactness envelope */
+#define AMPLI_E_CAPACITY (-5) /* compact call list overflowed; n_calls holds the needed size */
+#define AMPLI_E_RANGE (-6)    /* a count does not fit the kernels' integer envelope */
+
+typedef struct ampli_ctx ampli_ctx;
+
+int ampli_abi_version(void);
+const char *ampli_strerror(int code);
+/* number of HIP devices visible; 0 when there is none (never initialises a device) */
+int ampli_device_count(void);
+
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL
+ * to let the context create and own a non-blocking stream. */
+int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **out);
+void ampli_ctx_destroy(ampli_ctx *ctx);
+const char *ampli_last_error(ampli_ctx *ctx);
+int ampli_sync(ampli_ctx *ctx);        /* hipStreamSynchronize */
+void *ampli_stream(ampli_ctx *ctx);    /* the hipStream_t in use */
+
+/* memory plumbing */
+int ampli_pinned_alloc(size_t bytes, void **out);
+int ampli_pinned_free(void *p);
+int ampli_dev_alloc(ampli_ctx *ctx, size_t bytes, void **d_out);
+int ampli_dev_free(ampli_ctx *ctx, void *d_p);
+int ampli_copy_h2d(ampli_ctx *ctx, void *d_dst, const void *src, size_t bytes); /* async */
+int ampli_copy_d2h(ampli_ctx *ctx, void *dst, const void *d_src, size_t bytes); /* async */
+int ampli_memset_d(ampli_ctx *ctx, void *d_dst, int byte, size_t bytes);        /* async */
+
+/* events on the context's stream (HIP events; bench.py times kernels with these) */
+int ampli_event_create(void **ev);
+int ampli_event_destroy(void *ev);
+int ampli_event_record(ampli_ctx *ctx, void *ev);
+int ampli_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchronises on ev_stop */
+
+/*
+ * Accumulator table: what storeGermlineStatistics + the record loop of
+ * estimateThresholds leave behind per (position, nucleotide), as planes with the
+ * position index fastest.  All planes live in one buffer of ampli_acc_bytes(P)
+ * bytes; ampli_acc_bind carves the pointers.  Plane order in the buffer:
+ *   snt  double [2][4][P]  sum of X_s + float(RD_s)*float(C) over qualifying records   (EE:1597,1599)
+ *   srd  int64  [2][4][P]  sum of RD_s over qualifying records                         (EE:1598,1600)
+ *   cnt  int32  [4][P]     qualifying records                                          (EE:1606)
+ *   nrec int32  [P]        all records of the position = Value_Hash.count(key)         (EE:1659)
+ *   gm_n int32  [4][P]     records qualifying for Germ_Max                             (EE:1251)
+ *   gm_first    int32 [4][P]  global sample index of the first qualifying record (INT32_MAX: none)
+ *   gm_first_af float [4][P]  its AF (the reference discards it, EE:1258-1261; kept to merge shards)
+ *   gm_rest     float [4][P]  max AF over the later qualifying records (-inf: none)    (EE:1263-1270)
+ * [2] = strand (0 forward, 1 reverse), [4] = nucleotide A,C,G,T.
+ * snt|srd|cnt|nrec|gm_n are plain sums over samples: shards merge by addition
+ * (RCCL all-reduce SUM per dtype); the gm_* triple merges in sample order
+ * (ampli_acc_merge).
+ */
+typedef struct ampli_acc_table {
+    int64_t P;
+    double *snt;
+    int64_t *srd;
+    int32_t *cnt;
+    int32_t *nrec;
+    int32_t *gm_n;
+    int32_t *gm_first;
+    float *gm_first_af;
+    float *gm_rest;
+} ampli_acc_table;
+
+size_t ampli_acc_bytes(int64_t P);
+int ampli_acc_bind(void *base, int64_t P, ampli_acc_table *out);
+
+/*
+ * error_reduce -- replaces the per-line derivation of storeGermlineStatistics
+ * (EE:1149-1232), its running Germ_Max (EE:1251-1296 + C/G/T clones) and the
+ * gate/accumulate loop of estimateThresholds (EE:1565-1631 + clones) for S
+ * samples.  first_sample = global index of sample 0 of this shard.
+ * C, coverage_cutoff as the reference's C_value / coverage_cutoff after its
+ * defaulting (EE:372-388).  d_acc: device table (fully overwritten).
+ */
+int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E,
+                       const uint32_t *d_dup_off, int32_t S, int32_t first_sample, float C,
+                       int32_t coverage_cutoff, const ampli_acc_table *d_acc);
+
+/*
+ * acc_merge -- ordered combine of nparts partial tables (parts[0] = earliest
+ * samples) into d_dst (may alias parts[0]).  Sums add; the germ-max triple
+ * composes as the reference's sequential state machine would.  This is the
+ * local half of the multi-GPU merge and of in-GPU sample splitting.
+ */
+int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_acc_table *d_parts,
+                    int32_t nparts);
+
+/* Byte regions of a table buffer for the multi-GPU merge: [0, sum_bytes) holds the planes that merge by
+ * addition (snt | srd | cnt | nrec | gm_n; reduce each with its own dtype), [gm_offset, gm_offset+gm_bytes)
+ * holds gm_n | gm_first | gm_first_af | gm_rest (all-gather it BEFORE gm_n is reduced). */
+int ampli_acc_regions(int64_t P, size_t *sum_bytes, size_t *gm_offset, size_t *gm_bytes);
+
+/* gm_merge -- fold nparts gathered gm regions (region k = shard k, ascending sample order, laid out
+ * back to back, gm_bytes each) into d_dst's germ-max planes.  The sequential state machine of
+ * EE:1251-1271 composes over shards exactly as ampli_acc_merge does. */
+int ampli_gm_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const void *d_regions, int32_t nparts);
+
+/*
+ * error_finalize -- replaces the quorum/divide/NaN logic of estimateThresholds
+ * (EE:1659-1714 + clones) and the Germ_Max sentinel rule (EE:1260,1318,1374,1431).
+ *   d_rate [2][4][P] float : float(snt)/float(srd)                       (EE:1679-1680)
+ *   d_code [4][P]    uint8 : 0 estimate, 1 below quorum (EE:1659), 2 NaN (EE:1682)
+ *   d_thr  [2][4][P] float : the value AmpliSolveVariantCalling reads back from the table text:
+ *                            stof(sprintf("%f", rate)) (EE:1704 -> VC:889-890), 0.01f for code != 0
+ *                            (EE:2680-2684); computed in exact integer arithmetic on the device
+ *   d_germ_val [4][P] float, d_germ_present [4][P] uint8 : Germ_Max cell (EE:2807-2849)
+ *   d_flags [1] int32 : bit 0 set when a sum left the exactness envelope
+ * Any output pointer except d_code/d_rate may be NULL.
+ */
+int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc, float C,
+                         int32_t coverage_cutoff, float *d_rate, uint8_t *d_code, float *d_thr,
+                         float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
+
+/* one emitted call (VC:898 true) */
+typedef struct ampli_call {
+    int32_t sample;   /* index into the T axis of this launch */
+    int32_t record;   /* r in [0, R) */
+    int32_t alt;      /* 0..3 = A,C,G,T */
+    int32_t pad;
+    double q_fw, q_bw;            /* VC:895-896 */
+    float af, af_fw, af_bw, pad2; /* VC:772-817: the reported VAFs */
+} ampli_call;
+
+#define AMPLI_POISSON_FULL 0      /* evaluate all 6 scores of every record, as the reference does */
+#define AMPLI_POISSON_PREFILTER 1 /* skip scores an exact bound proves < 5 (identical outputs) */
+
+/*
+ * poisson_call -- replaces the per-line core of callVariants (VC:752-898 and
+ * its 11 clones) with mutationRulesPoissonQualityScore / kf_gammaq / kf_lgamma
+ * (VC:3721-3884) for T tumour samples.
+ *   d_thr [2][4][P] as produced by error_finalize or parsed from the table (std::stof, VC:889-890)
+ *   d_ref_code [P]  0..3 = A,C,G,T; 255 = reference base not in ACGT -> record skipped (VC:3290)
+ *   d_call_mask [T][R] uint8: bit a set = alt nucleotide a called at that record
+ *   d_calls / capacity / d_n_calls: optional compact list of emitted calls (unordered; sort by
+ *     (sample, record, alt) to get the reference's emission order); *d_n_calls counts all calls,
+ *     entries beyond capacity are dropped.  d_n_calls must be zeroed by the caller (ampli_memset_d).
+ *   d_q [T][R][4][2] double, optional dense scores (Q_fw,Q_bw per nucleotide; -1 = not evaluated;
+ *     requires mode FULL); d_af [T][R][4][3] float optional dense {AF, AF_fw, AF_bw}.
+ */
+int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E,
+                       const uint32_t *d_ext_pos, int32_t T, const float *d_thr,
+                       const uint8_t *d_ref_code, int32_t coverage_cutoff, int32_t mode,
+                       uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+                       unsigned long long *d_n_calls, double *d_q, float *d_af);
+
+/* scalar scorer on the device for known-answer tests: q[i] = score(k[i], rd[i], err[i]),
+ * p[i] = 1 - kf_gammaq(k, rd*err) (VC:3834-3884).  Either output may be NULL. */
+int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err,
+                      int64_t n, double *d_q, double *d_p);
+/* text round trip on the device for known-answer tests: out[i] = stof(sprintf("%f", in[i])) */
+int ampli_roundtrip_batch(ampli_ctx *ctx, const float *d_in, int64_t n, float *d_out);
+
+/* deterministic synthetic panel generated in HBM: fills recs[n_samples][P][8]
+ * for samples [first_sample, first_sample+n_samples) of panel `seed`; tumour != 0 spikes SNVs.
+ * Bit-identical to ampli_synth_record() on the host (amplisolve_amd/csrc/ampli_synth.h). */
+int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int32_t n_samples,
+                     int32_t first_sample, uint64_t seed, int32_t depth, int32_t tumour);
+int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t seed);
+
+/* tuning knobs (0 = automatic): waves are fixed at 4 per workgroup */
+int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reserved);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMPLISOLVE_HIP_H */

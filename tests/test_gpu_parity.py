@@ -1,0 +1,287 @@
+"""GPU parity: HIP kernels (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar: bit-exact for integer planes, counts, codes, masks and for everything the
+kernels compute with the reference's own operation sequence (double sums inside
+the exactness envelope, fp32 rates, the text round trip); 1e-6 on p-values / Q.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from tests.helpers import SEED, edge_case_recs, synth_recs, synth_ref
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL = 1e-6  # north_star: "within 1e-6 on the Poisson p-values / error rates"
+
+
+def _t(x):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def assert_acc_equal(acc, ref):
+    for name, plane in acc.planes().items():
+        got = plane.cpu().numpy()
+        exp = ref[name]
+        if name in ("gm_first", "gm_first_af", "gm_rest"):
+            # state only defined where a record qualified / a later record exists
+            n = ref["gm_n"]
+            m = n > 0 if name != "gm_rest" else n > 1
+            assert np.array_equal(got[m].view(np.int32), exp[m].view(np.int32)), name
+        else:
+            assert np.array_equal(got.view(np.int64 if got.dtype.itemsize == 8 else np.int32),
+                                  exp.view(np.int64 if exp.dtype.itemsize == 8 else np.int32)), name
+
+
+def assert_final_equal(fin, ref):
+    assert np.array_equal(fin.code.cpu().numpy(), ref["code"])
+    assert np.array_equal(fin.rate.cpu().numpy().view(np.int32), ref["rate"].view(np.int32))
+    assert np.array_equal(fin.thr.cpu().numpy().view(np.int32), ref["thr"].view(np.int32))
+    assert np.array_equal(fin.germ_present.cpu().numpy(), ref["germ_present"])
+    m = ref["germ_present"] > 0
+    assert np.array_equal(fin.germ_val.cpu().numpy()[m].astype(np.float64), ref["germ_val"][m])
+
+
+def test_synth_device_matches_host(ctx):
+    for tumour in (False, True):
+        d = ctx.synth_fill(777, 5, first_sample=3, depth=2000, tumour=tumour).cpu().numpy()
+        h = synth_recs(777, 5, first=3, depth=2000, tumour=tumour)
+        assert np.array_equal(d, h)
+    assert np.array_equal(ctx.synth_ref(777).cpu().numpy(), synth_ref(777))
+
+
+@pytest.mark.parametrize("P,S,splits", [(1, 1, 0), (63, 3, 0), (64, 4, 1), (65, 5, 2), (1000, 32, 0), (1000, 33, 3),
+                                        (4097, 37, 0), (10000, 32, 0)])
+def test_error_reduce_synthetic(ctx, P, S, splits):
+    recs = synth_recs(P, S)
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    assert ref["order_sensitive"] == 0
+    ctx.set_tuning(splits)
+    acc = ctx.error_reduce(_t(recs), P, 0.002, 100)
+    ctx.set_tuning(0)
+    assert_acc_equal(acc, ref)
+    fin = ctx.error_finalize(acc, 0.002, 100)
+    assert_final_equal(fin, orc.error_finalize(ref))
+    assert int(fin.flags.item()) == 0
+
+
+@pytest.mark.parametrize("C,cov", [(0.002, 100), (0.01, 50), (0.0005, 1), (0.002, 1000)])
+def test_error_reduce_edge_cases(ctx, C, cov):
+    rng = np.random.default_rng(7)
+    P, S = 517, 41
+    recs = edge_case_recs(P, S, rng)
+    ref = orc.error_reduce(recs, P, C, cov)
+    acc = ctx.error_reduce(_t(recs), P, C, cov)
+    assert_acc_equal(acc, ref)
+    assert_final_equal(ctx.error_finalize(acc, C, cov), orc.error_finalize(ref))
+
+
+def test_error_reduce_all_absent_and_empty_quorum(ctx):
+    P, S = 130, 9
+    recs = np.zeros((S, P, 8), np.int32)
+    recs[:, :, 0] = np.iinfo(np.int32).min  # no sample has any line: n = 0 -> NaN branch (EE:1682)
+    recs[:, 5] = [0, 0, 0, 500, 0, 0, 0, 500]  # one clean position
+    ref = orc.error_reduce(recs, P)
+    acc = ctx.error_reduce(_t(recs), P)
+    assert_acc_equal(acc, ref)
+    fin = ctx.error_finalize(acc)
+    assert_final_equal(fin, orc.error_finalize(ref))
+    code = fin.code.cpu().numpy()
+    assert (code[:, 0] == 2).all() and (code[:3, 5] == 0).all()
+
+
+def test_error_reduce_with_extra_occurrences(ctx):
+    """Positions listed twice (or three times) per file: every line is a record."""
+    rng = np.random.default_rng(11)
+    P, S = 300, 13
+    mult = np.zeros(P, np.int64)
+    mult[rng.choice(P, 40, replace=False)] = 1
+    mult[rng.choice(P, 5, replace=False)] = 2
+    dup_off = np.concatenate([[0], np.cumsum(mult)]).astype(np.uint32)
+    E = int(dup_off[-1])
+    base = synth_recs(P, S)
+    extra = edge_case_recs(E, S, rng)
+    recs = np.concatenate([base, extra], axis=1)
+    ref = orc.error_reduce(recs, P, 0.002, 100, E=E, dup_off=dup_off)
+    acc = ctx.error_reduce(_t(recs), P, 0.002, 100, E=E, dup_off=_t(dup_off))
+    assert_acc_equal(acc, ref)
+    assert_final_equal(ctx.error_finalize(acc), orc.error_finalize(ref))
+
+
+def test_shard_merge_matches_single_pass(ctx):
+    """Sample shards merged in order == one pass (the multi-GPU merge)."""
+    P, S = 2000, 48
+    recs = synth_recs(P, S)
+    full = orc.error_reduce(recs, P)
+    cuts = [0, 7, 8, 30, 48]
+    parts = [ctx.error_reduce(_t(recs[a:b]), P, first_sample=a) for a, b in zip(cuts[:-1], cuts[1:])]
+    merged = ctx.acc_merge(parts)
+    assert_acc_equal(merged, full)
+    # oracle's own merge agrees too
+    o = orc.error_reduce(recs[:7], P)
+    for a, b in zip(cuts[1:-1], cuts[2:]):
+        o = orc.acc_merge(o, orc.error_reduce(recs[a:b], P, first_sample=a))
+    for k in ("snt", "srd", "cnt", "nrec", "gm_n"):
+        assert np.array_equal(o[k], full[k])
+    # all-reduce style: SUM planes added, gm triples gathered and folded
+    import torch
+
+    dst = ctx.new_acc(P)
+    for name in ("snt", "srd", "cnt", "nrec"):
+        getattr(dst, name).copy_(sum(getattr(p, name) for p in parts))
+    _, gm_off, gm_bytes = ctx.regions(P)
+    gathered = torch.cat([p.buf[gm_off: gm_off + gm_bytes] for p in parts])
+    ctx.gm_merge(dst, gathered, len(parts))
+    assert_acc_equal(dst, full)
+
+
+def test_text_roundtrip_device(ctx):
+    import torch
+
+    rng = np.random.default_rng(3)
+    vals = np.concatenate([
+        rng.random(200000, dtype=np.float32) * np.float32(0.06),
+        (rng.random(100000, dtype=np.float32) * 20).astype(np.float32),
+        np.float32(10.0) ** rng.uniform(-12, 3, 100000).astype(np.float32),
+        np.array([0, 1e-7, 4.9e-7, 5e-7, 5.1e-7, 1.5e-6, 2.5e-6, 0.002, 0.01, 0.05, 1, 15.9999, 16, 17.5, 1e6, 1e-45, 3e38], np.float32),
+        (np.arange(0, 60000, dtype=np.float64) * 1e-6 + 5e-7).astype(np.float32),  # decimal ties
+    ])
+    got = ctx.roundtrip_batch(torch.from_numpy(vals).cuda()).cpu().numpy()
+    exp = np.array([orc.lib().oracle_text_roundtrip(float(v)) for v in vals], np.float32)
+    assert np.array_equal(got.view(np.int32), exp.view(np.int32))
+
+
+def test_scorer_against_oracle(ctx):
+    import torch
+
+    rng = np.random.default_rng(5)
+    n = 400000
+    k = rng.integers(0, 60, n).astype(np.int32)
+    k[: n // 4] = rng.integers(0, 3000, n // 4)
+    rd = rng.integers(0, 60000, n).astype(np.int32)
+    err = rng.choice(np.array([0.002, 0.01, 0.0005, 0.05, 0.0, -1.0, 0.002189, 0.000123, 0.3], np.float32), n)
+    q, p = ctx.score_batch(_t(k), _t(rd), _t(err))
+    q, p = q.cpu().numpy(), p.cpu().numpy()
+    qo, po = orc.score_batch(k, rd, err)
+    assert np.array_equal(np.isnan(p), np.isnan(po))
+    m = ~np.isnan(po)
+    assert np.max(np.abs(p[m] - po[m])) <= Q_TOL  # absolute on p
+    rel = np.abs(p[m] - po[m]) / np.maximum(np.abs(po[m]), 1e-300)
+    big = np.abs(po[m]) > 1e-10
+    assert np.max(rel[big]) <= Q_TOL
+    mq = ~np.isnan(qo)
+    assert np.max(np.abs(q[mq] - qo[mq])) <= 1e-5  # Q = -10 log10 p: 1e-6 relative on p is 4.3e-6 on Q
+    # the gate decision (Q >= 5) must agree except within rounding of the boundary
+    dis = (q[mq] >= 5) != (qo[mq] >= 5)
+    assert not dis.any() or np.all(np.abs(qo[mq][dis] - 5) < 1e-9)
+
+
+@pytest.mark.parametrize("P,T", [(1, 1), (255, 3), (257, 5), (3000, 8)])
+def test_poisson_call_synthetic(ctx, P, T):
+    S = 24
+    normals = synth_recs(P, S)
+    fin = orc.error_finalize(orc.error_reduce(normals, P))
+    ref_code = synth_ref(P)
+    trecs = synth_recs(P, T, tumour=True)
+    exp = orc.poisson_call(trecs, P, fin["thr"], ref_code, 100)
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    full = ctx.poisson_call(_t(trecs), P, _t(fin["thr"]), _t(ref_code), 100, mode=POISSON_FULL, dense_q=True, dense_af=True,
+                            capacity=4 * P * T + 16)
+    assert np.array_equal(full["call_mask"].cpu().numpy(), exp["call_mask"])
+    q, qo = full["q"].cpu().numpy(), exp["q"]
+    assert np.array_equal(q == -1, qo == -1)
+    assert np.max(np.abs(q - qo)) <= 1e-5
+    assert np.array_equal(full["af"].cpu().numpy().view(np.int32), exp["af"].view(np.int32))
+    pre = ctx.poisson_call(_t(trecs), P, _t(fin["thr"]), _t(ref_code), 100, mode=POISSON_PREFILTER, capacity=4 * P * T + 16)
+    assert np.array_equal(pre["call_mask"].cpu().numpy(), exp["call_mask"])
+    # compact list == mask, with the oracle's Q and VAFs
+    for res in (full, pre):
+        calls = ctx.read_calls(res)
+        t_i, r_i = np.nonzero(exp["call_mask"])
+        n_exp = sum(bin(int(v)).count("1") for v in exp["call_mask"][t_i, r_i])
+        assert len(calls) == n_exp
+        for c in calls:
+            assert exp["call_mask"][c["sample"], c["record"]] >> c["alt"] & 1
+            assert abs(c["q_fw"] - qo[c["sample"], c["record"], c["alt"], 0]) <= 1e-5
+            assert abs(c["q_bw"] - qo[c["sample"], c["record"], c["alt"], 1]) <= 1e-5
+            assert np.float32(c["af"]) == exp["af"][c["sample"], c["record"], c["alt"], 0]
+
+
+def test_poisson_call_edge_cases(ctx):
+    """Special thresholds (-1 -> Q=-888, 0 -> magic 0.0010008), non-ACGT reference, absent records, extras."""
+    rng = np.random.default_rng(13)
+    P, T, E = 400, 6, 37
+    trecs = edge_case_recs(P + E, T, rng)
+    # lift some cells to strong variants so calls exist
+    trecs[:, ::7, :] = np.array([30, 0, 0, 400, 25, 0, 0, 380], np.int32)
+    thr = rng.choice(np.array([0.002, 0.01, 0.0, -1.0, 0.000731, 0.05], np.float32), size=(2, 4, P)).astype(np.float32)
+    ref_code = rng.integers(0, 4, P).astype(np.uint8)
+    ref_code[::11] = 255
+    ext_pos = rng.integers(0, P, E).astype(np.uint32)
+    exp = orc.poisson_call(trecs, P, thr, ref_code, 100, E=E, ext_pos=ext_pos)
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    for mode in (POISSON_FULL, POISSON_PREFILTER):
+        res = ctx.poisson_call(_t(trecs), P, _t(thr), _t(ref_code), 100, mode=mode, E=E, ext_pos=_t(ext_pos),
+                               dense_q=(mode == POISSON_FULL))
+        assert np.array_equal(res["call_mask"].cpu().numpy(), exp["call_mask"])
+        if mode == POISSON_FULL:
+            q = res["q"].cpu().numpy()
+            assert np.array_equal(q == -1, exp["q"] == -1) and np.max(np.abs(q - exp["q"])) <= 1e-5
+    assert exp["call_mask"].any()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE config 3 (100k x 256 normals x 96 tumours) through size-independent properties."""
+    import torch
+
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    P, S, T = 100_000, 256, 96
+    recs = ctx.synth_fill(P, S)
+    acc = ctx.error_reduce(recs, P)
+    # (1) shard invariance: two sample shards merged in order == one pass, bit for bit
+    a = ctx.error_reduce(recs[:100], P, first_sample=0)
+    b = ctx.error_reduce(recs[100:], P, first_sample=100)
+    m = ctx.acc_merge([a, b])
+    for name, plane in acc.planes().items():
+        other = m.planes()[name]
+        if name in ("gm_first", "gm_first_af"):
+            sel = acc.gm_n > 0
+            assert torch.equal(plane[sel], other[sel]), name
+        elif name == "gm_rest":
+            sel = acc.gm_n > 1
+            assert torch.equal(plane[sel], other[sel]), name
+        else:
+            assert torch.equal(plane, other), name
+    # (2) conservation: nrec == number of present records; srd sums bounded by total depth
+    present = (recs[:, :, 0] != torch.iinfo(torch.int32).min)
+    assert torch.equal(acc.nrec.long(), present.sum(0))
+    assert bool((acc.cnt <= acc.nrec.unsqueeze(0)).all())
+    # (3) idempotence
+    acc2 = ctx.error_reduce(recs, P)
+    assert torch.equal(acc.buf, acc2.buf)
+    # (4) oracle on a slice of positions (records are independent across positions)
+    sl = slice(31_000, 31_900)
+    ref = orc.error_reduce(recs[:, sl].cpu().numpy(), 900)
+    assert np.array_equal(acc.snt[:, :, sl].cpu().numpy(), ref["snt"])
+    assert np.array_equal(acc.srd[:, :, sl].cpu().numpy(), ref["srd"])
+    assert np.array_equal(acc.cnt[:, sl].cpu().numpy(), ref["cnt"])
+    fin = ctx.error_finalize(acc)
+    assert int(fin.flags.item()) == 0
+    reff = orc.error_finalize(ref)
+    assert np.array_equal(fin.thr[:, :, sl].cpu().numpy().view(np.int32), reff["thr"].view(np.int32))
+    # (5) calling: prefilter mode == full mode, and the oracle on a slice
+    trecs = ctx.synth_fill(P, T, tumour=True)
+    refc = ctx.synth_ref(P)
+    full = ctx.poisson_call(trecs, P, fin.thr, refc, 100, mode=POISSON_FULL)
+    pre = ctx.poisson_call(trecs, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 20)
+    assert torch.equal(full["call_mask"], pre["call_mask"])
+    n_calls = int(pre["n_calls"].item())
+    bits = sum(int(((pre["call_mask"] >> a) & 1).sum()) for a in range(4))
+    assert n_calls == bits and n_calls > 0
+    exp = orc.poisson_call(trecs[:4, sl].cpu().numpy(), 900, fin.thr[:, :, sl].cpu().numpy(), refc[sl].cpu().numpy(), 100, dense=False)
+    assert np.array_equal(pre["call_mask"][:4, sl].cpu().numpy(), exp["call_mask"])
