@@ -77,7 +77,7 @@ class Context:
             raise AmpliError("no MI355X visible: libamplisolve_hip.so has no CPU fallback")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
-        stream = None if own_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = C.c_void_p(-1) if own_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         h = C.c_void_p()
         rc = self.lib.ampli_ctx_create(device, stream, C.byref(h))
         if rc != 0:

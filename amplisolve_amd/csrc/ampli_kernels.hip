@@ -83,11 +83,11 @@ extern "C" int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **ou
     if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return AMPLI_E_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
-    if (stream) {
-        ctx->stream = (hipStream_t)stream;
-    } else {
+    if (stream == AMPLI_STREAM_OWN) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return AMPLI_E_HIP; }
         ctx->own_stream = true;
+    } else {
+        ctx->stream = (hipStream_t)stream; // NULL = the device's default (null) stream
     }
     *out = ctx;
     return AMPLI_OK;

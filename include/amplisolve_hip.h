@@ -64,8 +64,10 @@ const char *ampli_strerror(int code);
 /* number of HIP devices visible; 0 when there is none (never initialises a device) */
 int ampli_device_count(void);
 
-/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL
- * to let the context create and own a non-blocking stream. */
+/* stream: the hipStream_t to enqueue on (e.g. torch's current stream); NULL is the
+ * device's default (null) stream; AMPLI_STREAM_OWN lets the context create and own a
+ * non-blocking stream (which does not synchronise with the null stream). */
+#define AMPLI_STREAM_OWN ((void *)(intptr_t)-1)
 int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **out);
 void ampli_ctx_destroy(ampli_ctx *ctx);
 const char *ampli_last_error(ampli_ctx *ctx);

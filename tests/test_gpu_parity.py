@@ -263,7 +263,8 @@ def test_full_size_properties(ctx):
     assert bool((acc.cnt <= acc.nrec.unsqueeze(0)).all())
     # (3) idempotence
     acc2 = ctx.error_reduce(recs, P)
-    assert torch.equal(acc.buf, acc2.buf)
+    for name, plane in acc.planes().items():  # (the padding between planes is not written)
+        assert torch.equal(plane, acc2.planes()[name]), name
     # (4) oracle on a slice of positions (records are independent across positions)
     sl = slice(31_000, 31_900)
     ref = orc.error_reduce(recs[:, sl].cpu().numpy(), 900)
