@@ -702,6 +702,139 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// poisson_call, prefilter mode: streaming pass + LDS work queue.
+// Most (record, alt) pairs are settled by integer/one-multiply tests (coverage,
+// k == 0, k <= m: ampli_prefilter_nocall).  The survivors -- real variants and
+// noisy cells, a few per cent -- are not evaluated in place (one slow lane would
+// stall its 63 neighbours for ~100 fp64 iterations); they are appended to a
+// queue in LDS and the whole workgroup drains it densely: two adjacent lanes
+// per item, one per strand.  Workgroup = 256 positions x PCQ_SAMPLES tumours.
+// ---------------------------------------------------------------------------
+constexpr int PCQ_SAMPLES = 8;
+constexpr int PCQ_CAP = 1024;          // queue capacity in items
+constexpr int PCQ_DRAIN_AT = PCQ_CAP - 3 * 256; // one more sample row (<= 768 items) always fits
+
+struct PcqShared {
+    int item[8][PCQ_CAP]; // SoA: {slot, alt, k_fw, d_fw, e_fw(bits), k_bw, d_bw, e_bw(bits)}
+    unsigned mask[PCQ_SAMPLES][64]; // 256 mask bytes per sample row, as words for LDS atomics
+    int qn;
+};
+
+__device__ __forceinline__ void pcq_drain(PcqShared &sh, const int n_items, const int t0, const long long r0,
+                                          const long long R, const int4 *__restrict__ recs,
+                                          ampli_call *__restrict__ calls, const long long capacity,
+                                          unsigned long long *__restrict__ n_calls)
+{
+    const int tid = threadIdx.x;
+    for (int base = 0; base < 2 * n_items; base += 256) {
+        const int e = base + tid;
+        if (e < 2 * n_items) {
+            const int it = e >> 1, strand = e & 1;
+            const int k = sh.item[2 + 3 * strand][it];
+            const int d = sh.item[3 + 3 * strand][it];
+            const float err = __int_as_float(sh.item[4 + 3 * strand][it]);
+            const double q = ampli_poisson_score(k, d, err);
+            const double q_other = __shfl_xor(q, 1);
+            if (strand == 0 && q >= 5 && q_other >= 5) { // VC:898 (coverage was checked when the item was queued)
+                const int slot = sh.item[0][it], alt = sh.item[1][it];
+                const int dt = slot >> 8, lr = slot & 255;
+                atomicOr(&sh.mask[dt][lr >> 2], (1u << alt) << ((lr & 3) * 8));
+                if (n_calls) {
+                    const unsigned long long idx = atomicAdd(n_calls, 1ull);
+                    if (calls && (long long)idx < capacity) {
+                        const int t = t0 + dt;
+                        const long long r = r0 + lr;
+                        const size_t o = (size_t)t * R + r;
+                        const int4 a0 = recs[o * 2], a1 = recs[o * 2 + 1]; // L2-hot: streamed moments ago
+                        const int fw[4] = {a0.x, a0.y, a0.z, a0.w}, bw[4] = {a1.x, a1.y, a1.z, a1.w};
+                        const int FW = fw[0] + fw[1] + fw[2] + fw[3], BW = bw[0] + bw[1] + bw[2] + bw[3];
+                        ampli_call c;
+                        c.sample = t; c.record = (int)r; c.alt = alt; c.pad = 0;
+                        c.q_fw = q; c.q_bw = q_other;
+                        c.af = (float)(fw[alt] + bw[alt]) / (float)(FW + BW);   // VC:814-817
+                        c.af_fw = FW == 0 ? 0.0f : (float)fw[alt] / (float)FW;  // VC:785-790
+                        c.af_bw = BW == 0 ? 0.0f : (float)bw[alt] / (float)BW;  // VC:805-810
+                        c.pad2 = 0.0f;
+                        calls[idx] = c;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void poisson_call_queue_kernel(
+    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
+    const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
+    unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
+    unsigned long long *__restrict__ n_calls)
+{
+    __shared__ PcqShared sh;
+    const int tid = threadIdx.x;
+    const long long R = P + E;
+    const long long r0 = (long long)blockIdx.x * 256;
+    const long long r_raw = r0 + tid;
+    const bool valid = r_raw < R;
+    const long long r = valid ? r_raw : R - 1;
+    const long long p = r < P ? r : (long long)ext_pos[r - P];
+    const int t0 = blockIdx.y * PCQ_SAMPLES;
+    const int nt_rows = min(PCQ_SAMPLES, T - t0);
+
+    float th[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        th[0][nt] = thr[(0 * 4 + nt) * P + p]; // VC:887-890
+        th[1][nt] = thr[(1 * 4 + nt) * P + p];
+    }
+    const int ref = valid ? (int)ref_code[p] : 255;
+    for (int i = tid; i < PCQ_SAMPLES * 64; i += 256) (&sh.mask[0][0])[i] = 0u;
+    if (tid == 0) sh.qn = 0;
+    __syncthreads();
+
+    int4 n0 = recs[((size_t)t0 * R + r) * 2], n1 = recs[((size_t)t0 * R + r) * 2 + 1];
+    for (int dt = 0; dt < nt_rows; ++dt) {
+        const int4 r0v = n0, r1v = n1;
+        if (dt + 1 < nt_rows) { // prefetch the next sample row
+            const size_t o = ((size_t)(t0 + dt + 1) * R + r) * 2;
+            n0 = recs[o];
+            n1 = recs[o + 1];
+        }
+        const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
+        const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
+        const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
+        const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
+        const int RD = FW + BW;
+        const bool live = valid && r0v.x != AMPLI_ABSENT && ref <= 3 && FW >= cov && BW >= cov; // VC:898, VC:3290
+        if (live) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                if (nt == ref) continue;
+                const int k_fw = fw[nt], d_fw = RD - BW, k_bw = bw[nt], d_bw = BW; // VC:895-896
+                if (ampli_prefilter_nocall(k_fw, d_fw, th[0][nt]) || ampli_prefilter_nocall(k_bw, d_bw, th[1][nt])) continue;
+                const int slot = atomicAdd(&sh.qn, 1);
+                sh.item[0][slot] = (dt << 8) | tid;
+                sh.item[1][slot] = nt;
+                sh.item[2][slot] = k_fw; sh.item[3][slot] = d_fw; sh.item[4][slot] = __float_as_int(th[0][nt]);
+                sh.item[5][slot] = k_bw; sh.item[6][slot] = d_bw; sh.item[7][slot] = __float_as_int(th[1][nt]);
+            }
+        }
+        __syncthreads();
+        const int qn = sh.qn;
+        if (qn > PCQ_DRAIN_AT || dt + 1 == nt_rows) { // block-uniform
+            pcq_drain(sh, qn, t0, r0, R, recs, calls, capacity, n_calls);
+            __syncthreads();
+            if (tid == 0) sh.qn = 0;
+            __syncthreads();
+        }
+    }
+    // mask rows out, one byte per record
+    if (valid) {
+        for (int dt = 0; dt < nt_rows; ++dt)
+            call_mask[(size_t)(t0 + dt) * R + r_raw] = (unsigned char)((sh.mask[dt][tid >> 2] >> ((tid & 3) * 8)) & 0xFF);
+    }
+}
+
 __global__ void score_batch_kernel(const int *k, const int *rd, const float *err, const long long n, double *q, double *pv)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -904,10 +1037,16 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_FULL>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
                            (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
                            (long long)capacity, d_n_calls, d_q, d_af);
-    else
+    else if (d_af) // dense VAFs are a validation output: literal per-lane kernel
         hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_PREFILTER>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
                            (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
                            (long long)capacity, d_n_calls, d_q, d_af);
+    else {
+        dim3 qgrid((unsigned)((R + 255) / 256), (unsigned)((T + PCQ_SAMPLES - 1) / PCQ_SAMPLES));
+        hipLaunchKernelGGL(poisson_call_queue_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,
+                           (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
+                           (long long)capacity, d_n_calls);
+    }
     return check_launch(ctx, "poisson_call_kernel");
 }
 
