@@ -73,6 +73,28 @@ HOST_SYMBOLS = {
     "ampli_host_text_roundtrip_batch": (None, [vp, i64, vp]),
     "ampli_host_af_limit": (i32, [i32]),
     "ampli_host_prefilter_nocall": (C.c_int, [i32, i32, f32]),
+    "ampli_host_last_error": (C.c_char_p, []),
+    "ampli_host_cohort_load": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ampli_host_cohort_free": (None, [vp]),
+    "ampli_host_cohort_P": (i64, [vp]),
+    "ampli_host_cohort_E": (i64, [vp]),
+    "ampli_host_cohort_S": (i32, [vp]),
+    "ampli_host_cohort_walk_len": (i64, [vp]),
+    "ampli_host_cohort_recs": (vp, [vp]),
+    "ampli_host_cohort_dup_off": (vp, [vp]),
+    "ampli_host_cohort_ext_pos": (vp, [vp]),
+    "ampli_host_cohort_line_no": (vp, [vp]),
+    "ampli_host_cohort_ref_code": (vp, [vp]),
+    "ampli_host_cohort_dup_flag": (vp, [vp]),
+    "ampli_host_cohort_sample_name": (C.c_char_p, [vp, i32]),
+    "ampli_host_cohort_stats": (None, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
+    "ampli_host_position": (C.c_int, [vp, i64, C.c_char_p, C.c_int, C.POINTER(i32)]),
+    "ampli_host_sample_order": (C.c_int, [C.c_char_p, C.c_char_p, i64]),
+    "ampli_host_write_error_table": (C.c_int, [vp, vp, vp, vp, vp, C.c_char_p]),
+    "ampli_host_read_error_table": (C.c_int, [C.c_char_p, C.POINTER(vp), vp, i64]),
+    "ampli_host_run_error_estimation": (C.c_int, [C.c_char_p] * 8),
+    "ampli_host_run_variant_calling": (C.c_int, [C.c_char_p] * 5),
+    "ampli_host_fisher": (C.c_double, [C.c_int] * 4),
 }
 
 _hip = None

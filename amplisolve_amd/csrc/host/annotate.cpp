@@ -1,0 +1,73 @@
+// amplisolve_amd/csrc/host/annotate.cpp -- post-call annotation of the (sparse) emitted calls:
+// Fisher strand-bias test, +-10-mer context, homopolymer flag (VC:3307-3718, VC:3797-3814).
+#include <algorithm>
+#include <cmath>
+
+#include "host.hpp"
+
+namespace ampli {
+
+// Two-sided Fisher exact test as VC:3797-3814 forms it: N = a+b+c+d, r = a+c, n = c+d, sum of the
+// hypergeometric pmf over all k whose probability does not exceed that of the observed k = c.
+// The reference takes the pmf from Boost.Math (absent here, not vendored by the reference): this is an own
+// log-gamma pmf; probabilities within 1e-7 relative of the observed one count as ties (as R's fisher.test).
+// PARITY UNPINNED at the Boost boundary.
+double fisher_two_sided(int a, int b, int c, int d)
+{
+    const unsigned N = (unsigned)(a + b + c + d), r = (unsigned)(a + c), n = (unsigned)(c + d);
+    const unsigned max_for_k = std::min(r, n);
+    const unsigned min_for_k = (unsigned)std::max(0, (int)(r + n - N));
+    auto lchoose = [](double nn, double kk) { return std::lgamma(nn + 1) - std::lgamma(kk + 1) - std::lgamma(nn - kk + 1); };
+    const double ldenom = lchoose(N, n);
+    auto pmf = [&](unsigned k) { return std::exp(lchoose(r, k) + lchoose((double)N - r, (double)n - k) - ldenom); };
+    const double cutoff = pmf((unsigned)c);
+    double tmp_p = 0.0;
+    for (unsigned k = min_for_k; k < max_for_k + 1; ++k) {
+        const double p = pmf(k);
+        if (p <= cutoff * (1 + 1e-7)) tmp_p += p;
+    }
+    return tmp_p;
+}
+
+static std::string base_or(const Panel &p, const std::string &chrom, int pos, const char *missing)
+{
+    const int i = p.find(chrom, pos);
+    return i < 0 ? std::string(missing) : p.ref_base[i];
+}
+
+// offsets -10..-1; a position outside the panel contributes "-|", except offsets -6, -3 and -1 which
+// contribute a bare "-" (VC:3389, 3425, 3449)
+std::string kmer_down(const Panel &p, const std::string &chrom, int pos)
+{
+    std::string s;
+    for (int o = 10; o >= 1; --o) s += base_or(p, chrom, pos - o, (o == 6 || o == 3 || o == 1) ? "-" : "-|");
+    return s;
+}
+
+// offsets +1..+10; missing -> "-|", except +10 -> "-" (VC:3604)
+std::string kmer_up(const Panel &p, const std::string &chrom, int pos)
+{
+    std::string s;
+    for (int o = 1; o <= 10; ++o) s += base_or(p, chrom, pos + o, o == 10 ? "-" : "-|");
+    return s;
+}
+
+// VC:3615-3718: count A/C/G/T over both context strings plus the substituted base; flag when the two most
+// frequent bases of any pair exceed 18 of the 21
+int homopolymer_test(const std::string &down, const std::string &up, char sub)
+{
+    int n[4] = {0, 0, 0, 0};
+    auto add = [&](char ch) {
+        if (ch == 'A') ++n[0];
+        else if (ch == 'C') ++n[1];
+        else if (ch == 'G') ++n[2];
+        else if (ch == 'T') ++n[3];
+    };
+    add(sub);
+    for (char ch : down) add(ch);
+    for (char ch : up) add(ch);
+    if (n[0] + n[1] > 18 || n[0] + n[2] > 18 || n[0] + n[3] > 18 || n[1] + n[2] > 18 || n[1] + n[3] > 18 || n[3] + n[2] > 18) return 1;
+    return 0;
+}
+
+} // namespace ampli

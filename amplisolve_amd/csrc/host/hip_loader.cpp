@@ -1,0 +1,66 @@
+// amplisolve_amd/csrc/host/hip_loader.cpp
+#include "hip_loader.hpp"
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <mutex>
+
+#include "host.hpp"
+
+namespace ampli {
+
+static HipApi g_api;
+static bool g_ok = false;
+static std::string g_why;
+static std::once_flag g_once;
+
+static std::string own_dir()
+{
+    Dl_info info;
+    if (dladdr((void *)&own_dir, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t s = p.rfind('/');
+        if (s != std::string::npos) return p.substr(0, s);
+    }
+    return ".";
+}
+
+static void load()
+{
+    std::vector<std::string> cands;
+    if (const char *e = getenv("AMPLISOLVE_HIP_LIB")) cands.emplace_back(e);
+    const std::string d = own_dir();
+    cands.push_back(d + "/libamplisolve_hip.so");
+    cands.push_back(d + "/../lib/libamplisolve_hip.so");
+    cands.emplace_back("libamplisolve_hip.so");
+    void *h = nullptr;
+    for (auto &c : cands) {
+        h = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        g_why = dlerror();
+    }
+    if (!h) return;
+#define BIND(field, sym)                                                        \
+    *(void **)(&g_api.field) = dlsym(h, sym);                                   \
+    if (!g_api.field) { g_why = std::string("missing symbol ") + sym; return; }
+    BIND(abi_version, "ampli_abi_version") BIND(strerror_, "ampli_strerror") BIND(device_count, "ampli_device_count")
+    BIND(ctx_create, "ampli_ctx_create") BIND(ctx_destroy, "ampli_ctx_destroy") BIND(last_error, "ampli_last_error")
+    BIND(sync, "ampli_sync") BIND(pinned_alloc, "ampli_pinned_alloc") BIND(pinned_free, "ampli_pinned_free")
+    BIND(dev_alloc, "ampli_dev_alloc") BIND(dev_free, "ampli_dev_free") BIND(copy_h2d, "ampli_copy_h2d")
+    BIND(copy_d2h, "ampli_copy_d2h") BIND(memset_d, "ampli_memset_d") BIND(acc_bytes, "ampli_acc_bytes")
+    BIND(acc_bind, "ampli_acc_bind") BIND(error_reduce, "ampli_error_reduce") BIND(error_finalize, "ampli_error_finalize")
+    BIND(poisson_call, "ampli_poisson_call")
+#undef BIND
+    if (g_api.abi_version() != AMPLI_ABI_VERSION) { g_why = "libamplisolve_hip.so ABI version mismatch"; return; }
+    g_ok = true;
+}
+
+const HipApi *hip_api(std::string *why)
+{
+    std::call_once(g_once, load);
+    if (!g_ok && why) *why = g_why;
+    return g_ok ? &g_api : nullptr;
+}
+
+} // namespace ampli

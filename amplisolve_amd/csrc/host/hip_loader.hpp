@@ -1,0 +1,39 @@
+// amplisolve_amd/csrc/host/hip_loader.hpp -- run-time binding of libamplisolve_hip.so (include/amplisolve_hip.h).
+// The host library must load on a machine without ROCm devices (parsers, writers and their tests run there);
+// every compute entry point goes through this table and fails loudly when the library is absent.
+#pragma once
+#include <string>
+
+#include "../../../include/amplisolve_hip.h"
+
+namespace ampli {
+
+struct HipApi {
+    int (*abi_version)(void);
+    const char *(*strerror_)(int);
+    int (*device_count)(void);
+    int (*ctx_create)(int, void *, ampli_ctx **);
+    void (*ctx_destroy)(ampli_ctx *);
+    const char *(*last_error)(ampli_ctx *);
+    int (*sync)(ampli_ctx *);
+    int (*pinned_alloc)(size_t, void **);
+    int (*pinned_free)(void *);
+    int (*dev_alloc)(ampli_ctx *, size_t, void **);
+    int (*dev_free)(ampli_ctx *, void *);
+    int (*copy_h2d)(ampli_ctx *, void *, const void *, size_t);
+    int (*copy_d2h)(ampli_ctx *, void *, const void *, size_t);
+    int (*memset_d)(ampli_ctx *, void *, int, size_t);
+    size_t (*acc_bytes)(int64_t);
+    int (*acc_bind)(void *, int64_t, ampli_acc_table *);
+    int (*error_reduce)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, int32_t, float, int32_t,
+                        const ampli_acc_table *);
+    int (*error_finalize)(ampli_ctx *, const ampli_acc_table *, float, int32_t, float *, uint8_t *, float *, float *, uint8_t *,
+                          int32_t *);
+    int (*poisson_call)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, const float *,
+                        const uint8_t *, int32_t, int32_t, uint8_t *, ampli_call *, int64_t, unsigned long long *, double *,
+                        float *);
+};
+
+const HipApi *hip_api(std::string *why);
+
+} // namespace ampli

@@ -1,0 +1,99 @@
+// amplisolve_amd/csrc/host/host.hpp -- C++ host side of the two AmpliSolve command lines.
+//
+// Parsers, panel index, SoA packer, table reader/writer, annotation and the
+// pipelines that call libamplisolve_hip.so.  No arithmetic of the hot path
+// lives here.  EE:n / VC:n cite /root/reference/source_codes/AmpliSolve{ErrorEstimation,VariantCalling}.cpp.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/amplisolve_hip.h"
+
+namespace ampli {
+
+struct BedRow {
+    std::string chrom;
+    int start = -1, end = -1;
+};
+
+// The panel: unique positions in order of first appearance in the BED walk
+// (rows in file order, start..end inclusive, 1-based: EE:633-649, EE:2595-2606).
+struct Panel {
+    std::vector<BedRow> rows;
+    std::vector<std::string> chroms;                  // chrom id -> name
+    std::unordered_map<std::string, int> chrom_id;    // name -> id
+    std::vector<int32_t> pos_chrom, pos_coord;        // per unique position p
+    std::vector<uint32_t> walk;                       // BED walk (duplicates repeated) -> p
+    std::unordered_map<uint64_t, uint32_t> index;     // (chrom id << 32 | coord) -> p
+    std::vector<std::string> ref_base;                // per p, as read (case preserved)
+    std::vector<uint8_t> ref_code;                    // 0..3 = A,C,G,T (exact, upper case), 255 otherwise
+    std::vector<uint8_t> dup;                         // per p: listed more than once (EE:657-664)
+    // error-table columns, when the panel was loaded from positionSpecificNoise_*.txt (VC:430-576)
+    std::vector<std::string> thr_text[4], germ_text[4];
+
+    int64_t P() const { return (int64_t)pos_coord.size(); }
+    int find(const std::string &chrom, int coord) const;
+    int add_position(const std::string &chrom, int coord);
+    void set_ref(uint32_t p, const std::string &base);
+};
+
+// A directory of .PILEUP.ASEQ files packed into the record SoA of include/amplisolve_hip.h
+struct Cohort {
+    std::vector<std::string> paths;   // in visit order (EE:1081 / VC:672)
+    std::vector<std::string> names;   // sample names (EE:831)
+    int64_t P = 0, E = 0;
+    int32_t *recs = nullptr;          // [S][P+E][8], pinned when the HIP library is loaded
+    bool pinned = false;
+    std::vector<uint32_t> dup_off;    // [P+1]
+    std::vector<uint32_t> ext_pos;    // [E]
+    std::vector<int32_t> line_no;     // [S][P+E] data-line index inside the sample's file, -1 absent
+    int64_t n_lines = 0, n_offpanel = 0, n_irregular = 0, n_malformed = 0;
+    ~Cohort();
+    int S() const { return (int)paths.size(); }
+    int64_t R() const { return P + E; }
+};
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+// ---- panel.cpp ----
+void panel_from_bed(const std::string &bed_path, Panel &out);                   // throws Error
+void panel_load_refbases_file(Panel &p, const std::string &path);               // chrom pos base per line (EE:963)
+void panel_load_fasta(Panel &p, const std::string &fasta_path);                 // replaces `samtools faidx` (EE:644)
+void panel_write_interm_files(const Panel &p, const std::string &dir, int seed);// EE:601, 657-664
+// ---- aseq.cpp ----
+std::vector<std::pair<std::string, std::string>> list_count_files(const std::string &dir, const std::string &list_file); // EE:552-559, 794-841
+void cohort_load(const Panel &panel, const std::string &dir, const std::string &list_file, int n_threads, bool keep_line_no,
+                 bool print_irregular, Cohort &out);
+// ---- table.cpp ----
+std::string format_rate_cell(uint8_t code, float r_fw, float r_bw, bool is_ref);  // EE:1704, 2670-2688
+std::string format_germ_cell(uint8_t present, float v);                           // EE:2807-2849
+void write_error_table(const Panel &panel, const float *rate, const uint8_t *code, const float *germ_val,
+                       const uint8_t *germ_present, const std::string &path);
+void write_error_table_default(const Panel &panel, float default_error, const std::string &path); // EE:2948-3043
+void panel_from_error_table(const std::string &path, const std::string &dummy_vcf, Panel &out, std::vector<float> &thr); // VC:430-576
+// ---- hip_loader.cpp ----
+struct HipApi; // function pointers of libamplisolve_hip.so
+const HipApi *hip_api(std::string *why = nullptr); // nullptr when the library cannot be loaded
+// ---- pipeline.cpp ----
+struct EeArgs {
+    std::string panel_design, reference_genome, germline_dir, output_dir;
+    std::string C_value = "0.002", coverage_cutoff = "100", default_error = "0.01";
+    std::string refbases_file; // test hook: skip the FASTA, read chrom/pos/base lines
+};
+struct VcArgs {
+    std::string error_file, tumour_dir, output_dir, coverage_cutoff = "100", p_value = "0.05";
+};
+int run_error_estimation(const EeArgs &a);
+int run_variant_calling(const VcArgs &a);
+// ---- annotate.cpp ----
+double fisher_two_sided(int a, int b, int c, int d);                            // VC:3797-3814 (own hypergeometric pmf)
+std::string kmer_down(const Panel &p, const std::string &chrom, int pos);       // VC:3307-3458
+std::string kmer_up(const Panel &p, const std::string &chrom, int pos);         // VC:3461-3613
+int homopolymer_test(const std::string &down, const std::string &up, char sub); // VC:3615-3718
+
+} // namespace ampli

@@ -1,0 +1,142 @@
+// amplisolve_amd/csrc/host/host_api.cpp -- C ABI over the host library (include/amplisolve_host.h).
+#include <cstring>
+
+#include "../../../include/amplisolve_host.h"
+#include "host.hpp"
+
+using namespace ampli;
+
+struct ampli_host_cohort {
+    Panel panel;
+    Cohort cohort;
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+extern "C" const char *ampli_host_last_error(void) { return g_err.c_str(); }
+
+extern "C" int ampli_host_cohort_load(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
+                                      const char *aseq_dir, int n_threads, int keep_line_no, ampli_host_cohort **out)
+{
+    if (!bed_or_table || !out) return AMPLI_E_INVALID;
+    *out = nullptr;
+    auto *h = new ampli_host_cohort();
+    try {
+        if (is_error_table) {
+            std::vector<float> thr;
+            panel_from_error_table(bed_or_table, "", h->panel, thr);
+        } else {
+            panel_from_bed(bed_or_table, h->panel);
+            if (refbases_file && *refbases_file) panel_load_refbases_file(h->panel, refbases_file);
+            else if (fasta && *fasta) panel_load_fasta(h->panel, fasta);
+        }
+        if (aseq_dir && *aseq_dir) cohort_load(h->panel, aseq_dir, "", n_threads, keep_line_no != 0, false, h->cohort);
+        else h->cohort.P = h->panel.P();
+    } catch (const Error &e) {
+        g_err = e.msg;
+        delete h;
+        return e.code ? e.code : -1;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" void ampli_host_cohort_free(ampli_host_cohort *h) { delete h; }
+extern "C" int64_t ampli_host_cohort_P(const ampli_host_cohort *h) { return h->panel.P(); }
+extern "C" int64_t ampli_host_cohort_E(const ampli_host_cohort *h) { return h->cohort.E; }
+extern "C" int32_t ampli_host_cohort_S(const ampli_host_cohort *h) { return h->cohort.S(); }
+extern "C" int64_t ampli_host_cohort_walk_len(const ampli_host_cohort *h) { return (int64_t)h->panel.walk.size(); }
+extern "C" const int32_t *ampli_host_cohort_recs(const ampli_host_cohort *h) { return h->cohort.recs; }
+extern "C" const uint32_t *ampli_host_cohort_dup_off(const ampli_host_cohort *h) { return h->cohort.dup_off.data(); }
+extern "C" const uint32_t *ampli_host_cohort_ext_pos(const ampli_host_cohort *h) { return h->cohort.ext_pos.data(); }
+extern "C" const int32_t *ampli_host_cohort_line_no(const ampli_host_cohort *h) { return h->cohort.line_no.empty() ? nullptr : h->cohort.line_no.data(); }
+extern "C" const uint8_t *ampli_host_cohort_ref_code(const ampli_host_cohort *h) { return h->panel.ref_code.data(); }
+extern "C" const uint8_t *ampli_host_cohort_dup_flag(const ampli_host_cohort *h) { return h->panel.dup.data(); }
+extern "C" const char *ampli_host_cohort_sample_name(const ampli_host_cohort *h, int32_t s)
+{
+    return (s >= 0 && s < h->cohort.S()) ? h->cohort.names[s].c_str() : nullptr;
+}
+extern "C" void ampli_host_cohort_stats(const ampli_host_cohort *h, int64_t *lines, int64_t *offpanel, int64_t *irregular, int64_t *malformed)
+{
+    if (lines) *lines = h->cohort.n_lines;
+    if (offpanel) *offpanel = h->cohort.n_offpanel;
+    if (irregular) *irregular = h->cohort.n_irregular;
+    if (malformed) *malformed = h->cohort.n_malformed;
+}
+extern "C" int ampli_host_position(const ampli_host_cohort *h, int64_t p, char *chrom_out, int chrom_cap, int32_t *coord)
+{
+    if (p < 0 || p >= h->panel.P()) return AMPLI_E_INVALID;
+    const std::string &c = h->panel.chroms[h->panel.pos_chrom[p]];
+    if (chrom_out && chrom_cap > 0) { strncpy(chrom_out, c.c_str(), (size_t)chrom_cap - 1); chrom_out[chrom_cap - 1] = 0; }
+    if (coord) *coord = h->panel.pos_coord[p];
+    return 0;
+}
+
+extern "C" int ampli_host_write_error_table(const ampli_host_cohort *h, const float *rate, const uint8_t *code, const float *germ_val,
+                                            const uint8_t *germ_present, const char *path)
+{
+    try {
+        write_error_table(h->panel, rate, code, germ_val, germ_present, path);
+    } catch (const Error &e) {
+        g_err = e.msg;
+        return e.code ? e.code : -1;
+    }
+    return 0;
+}
+
+extern "C" int ampli_host_read_error_table(const char *path, ampli_host_cohort **out, float *thr_out, int64_t thr_capacity)
+{
+    auto *h = new ampli_host_cohort();
+    try {
+        std::vector<float> thr;
+        panel_from_error_table(path, "", h->panel, thr);
+        h->cohort.P = h->panel.P();
+        if (thr_out) {
+            if ((int64_t)thr.size() > thr_capacity) throw Error{AMPLI_E_INVALID, "thr buffer too small"};
+            memcpy(thr_out, thr.data(), thr.size() * sizeof(float));
+        }
+    } catch (const Error &e) {
+        g_err = e.msg;
+        delete h;
+        return e.code ? e.code : -1;
+    }
+    *out = h;
+    return 0;
+}
+
+extern "C" int ampli_host_run_error_estimation(const char *panel_design, const char *reference_genome, const char *germline_dir,
+                                               const char *C_value, const char *coverage_cutoff, const char *default_error,
+                                               const char *output_dir, const char *refbases_file)
+{
+    EeArgs a;
+    a.panel_design = panel_design; a.reference_genome = reference_genome ? reference_genome : ""; a.germline_dir = germline_dir;
+    a.C_value = C_value; a.coverage_cutoff = coverage_cutoff; a.default_error = default_error; a.output_dir = output_dir;
+    if (refbases_file) a.refbases_file = refbases_file;
+    return run_error_estimation(a);
+}
+
+extern "C" int ampli_host_run_variant_calling(const char *error_file, const char *tumour_dir, const char *output_dir,
+                                              const char *coverage_cutoff, const char *p_value)
+{
+    VcArgs a;
+    a.error_file = error_file; a.tumour_dir = tumour_dir; a.output_dir = output_dir; a.coverage_cutoff = coverage_cutoff; a.p_value = p_value;
+    return run_variant_calling(a);
+}
+
+extern "C" double ampli_host_fisher(int a, int b, int c, int d) { return fisher_two_sided(a, b, c, d); }
+
+extern "C" int ampli_host_sample_order(const char *dir, char *out, int64_t cap)
+{
+    try {
+        auto v = list_count_files(dir, "");
+        std::string s;
+        for (auto &f : v) s += f.second + "\n";
+        if ((int64_t)s.size() + 1 > cap) return AMPLI_E_INVALID;
+        memcpy(out, s.c_str(), s.size() + 1);
+        return (int)v.size();
+    } catch (const Error &e) {
+        g_err = e.msg;
+        return e.code ? e.code : -1;
+    }
+}

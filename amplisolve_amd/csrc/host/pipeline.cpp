@@ -1,0 +1,374 @@
+// amplisolve_amd/csrc/host/pipeline.cpp -- the two command lines, end to end.
+//   run_error_estimation  re-states main() of AmpliSolveErrorEstimation.cpp (EE:241-520)
+//   run_variant_calling   re-states main() + callVariants of AmpliSolveVariantCalling.cpp (VC:199-360, VC:633-3304)
+// Parsing / formatting happen here; sums, rates, p-values and the call gate come from libamplisolve_hip.so.
+#include <sys/stat.h>
+#include <sys/types.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+#include "hip_loader.hpp"
+#include "host.hpp"
+
+namespace ampli {
+
+namespace {
+
+void mkdir_p(const std::string &path) // generateFolder: `mkdir -p` (EE:3079-3086)
+{
+    std::string cur;
+    for (size_t i = 0; i <= path.size(); ++i) {
+        if (i == path.size() || path[i] == '/') {
+            if (!cur.empty()) mkdir(cur.c_str(), 0777);
+        }
+        if (i < path.size()) cur.push_back(path[i]);
+    }
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Dev {
+    const HipApi *api = nullptr;
+    ampli_ctx *ctx = nullptr;
+    std::vector<void *> allocs;
+    ~Dev()
+    {
+        if (ctx) {
+            for (void *p : allocs) api->dev_free(ctx, p);
+            api->ctx_destroy(ctx);
+        }
+    }
+    void check(int rc, const char *what)
+    {
+        if (rc != AMPLI_OK)
+            throw Error{rc, std::string(what) + ": " + api->strerror_(rc) + (ctx ? std::string(" -- ") + api->last_error(ctx) : "")};
+    }
+    void open()
+    {
+        std::string why;
+        api = hip_api(&why);
+        if (!api) throw Error{AMPLI_E_HIP, "libamplisolve_hip.so could not be loaded (" + why + "); there is no CPU fallback"};
+        if (api->device_count() <= 0) throw Error{AMPLI_E_HIP, "no MI355X visible; there is no CPU fallback"};
+        int dev = 0;
+        if (const char *e = getenv("AMPLISOLVE_DEVICE")) dev = atoi(e);
+        check(api->ctx_create(dev, nullptr, &ctx), "ampli_ctx_create");
+    }
+    template <class T> T *alloc(size_t n)
+    {
+        void *p = nullptr;
+        check(api->dev_alloc(ctx, n * sizeof(T), &p), "ampli_dev_alloc");
+        allocs.push_back(p);
+        return (T *)p;
+    }
+    template <class T> T *upload(const T *src, size_t n)
+    {
+        T *d = alloc<T>(n ? n : 1);
+        if (n) check(api->copy_h2d(ctx, d, src, n * sizeof(T)), "ampli_copy_h2d");
+        return d;
+    }
+    template <class T> void download(T *dst, const T *d, size_t n) { check(api->copy_d2h(ctx, dst, d, n * sizeof(T)), "ampli_copy_d2h"); }
+    void sync() { check(api->sync(ctx), "ampli_sync"); }
+};
+
+const char *kLine = "************************************************************************************************************************************";
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+int run_error_estimation(const EeArgs &a)
+{
+    try {
+        // EE:328-388: numeric conversion and defaults
+        float C_value = (float)std::atof(a.C_value.c_str());
+        int cov = std::atoi(a.coverage_cutoff.c_str());
+        const bool no_germlines = a.germline_dir == "not_available";
+        float default_error = 0.01f;
+        std::cout << kLine << "\n" << std::endl;
+        std::cout << "                                Error estimation required for AmpliSolveVariantCalling program \n" << std::endl;
+        std::cout << "                        MI355X-native build (amplisolve_amd); command line and files as AmpliSolveErrorEstimation\n" << std::endl;
+        std::cout << "Execution started under the following parameters:" << std::endl;
+        std::cout << "\t1. Panel design                                   : " << a.panel_design << std::endl;
+        std::cout << "\t2. Reference genome                               : " << a.reference_genome << std::endl;
+        if (no_germlines) {
+            default_error = (float)std::atof(a.default_error.c_str());
+            if (default_error > 0) {
+                std::cout << "\t3. Germline count dir                             : NO germline count files available. Estimation of error is based on platform-specific error level given by user equal to " << default_error << std::endl;
+            } else {
+                default_error = 0.01f;
+                std::cout << "\t3. Germline count dir                             : NO germline count files available. User gave wrong platform-specific error level and the estimation will be based on Error=" << default_error << std::endl;
+            }
+        } else {
+            std::cout << "\t3. Germline count dir                             : " << a.germline_dir << std::endl;
+        }
+        if (C_value <= 0) {
+            C_value = 0.002f;
+            std::cout << "\t4. C value                                         : User gave: " << a.C_value << ". The value is converted to 0.002" << std::endl;
+        } else {
+            std::cout << "\t4. C value                                        : " << C_value << std::endl;
+        }
+        if (cov <= 0) {
+            cov = 100;
+            std::cout << "\t5. Coverage cutoff                                  : User gave: " << a.coverage_cutoff << ". The value is converted 100" << std::endl;
+        } else {
+            std::cout << "\t5. Coverage cutoff                                : " << cov << std::endl;
+        }
+        std::cout << "\t6. Output dir                                     : " << a.output_dir << std::endl;
+
+        const std::string interm = a.output_dir + "/AmpliSolveErrorEstimation_interm_files"; // EE:414
+        mkdir_p(interm);
+        srand((unsigned)time(nullptr));
+        const int seed = rand() % 1000; // EE:581-584
+
+        double t0 = now_s();
+        Panel panel;
+        panel_from_bed(a.panel_design, panel);
+        if (!a.refbases_file.empty()) panel_load_refbases_file(panel, a.refbases_file);
+        else panel_load_fasta(panel, a.reference_genome);
+        panel_write_interm_files(panel, interm, seed);
+        std::cout << "\nRunning function generateReferenceBases: Reference bases and amplicon duplicated positions have generated"
+                  << "\n\t\t --> Parsed in total " << panel.rows.size() << " amplicons and annotated " << panel.walk.size() << " positions." << std::endl;
+        std::cout << "Running function storeReference: panel reference bases stored with success " << panel.P() << std::endl;
+        size_t ndup = 0;
+        for (auto d : panel.dup) ndup += d;
+        std::cout << "Running function storeDuplicates: panel duplicate positions stored with success " << ndup << std::endl;
+
+        if (no_germlines) { // EE:472-506
+            const std::string out = a.output_dir + "/positionSpecificNoise_default.txt";
+            write_error_table_default(panel, default_error, out);
+            std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
+            std::cout << "\n" << kLine << std::endl;
+            return 0;
+        }
+
+        double t1 = now_s();
+        Cohort co;
+        const std::string list_name = interm + "/" + std::to_string(seed) + "_germline_count_list_original.txt"; // EE:442
+        int threads = 0;
+        if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
+        cohort_load(panel, a.germline_dir, list_name, threads, false, true, co);
+        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.S() << " samples" << std::endl;
+        double t2 = now_s();
+        std::cout << "Running function storeGermlineStatistics:" << std::endl;
+
+        Dev dev;
+        dev.open();
+        const int64_t P = co.P, R = co.R();
+        int32_t *d_recs = dev.upload(co.recs, (size_t)co.S() * R * 8);
+        uint32_t *d_dup = co.E ? dev.upload(co.dup_off.data(), co.dup_off.size()) : nullptr;
+        void *d_accbuf = dev.alloc<char>(dev.api->acc_bytes(P));
+        ampli_acc_table acc;
+        dev.check(dev.api->acc_bind(d_accbuf, P, &acc), "ampli_acc_bind");
+        float *d_rate = dev.alloc<float>((size_t)P * 8), *d_germ = dev.alloc<float>((size_t)P * 4);
+        uint8_t *d_code = dev.alloc<uint8_t>((size_t)P * 4), *d_gp = dev.alloc<uint8_t>((size_t)P * 4);
+        int32_t *d_flags = dev.alloc<int32_t>(1);
+        dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
+        dev.check(dev.api->error_reduce(dev.ctx, d_recs, P, co.E, d_dup, co.S(), 0, C_value, cov, &acc), "ampli_error_reduce");
+        std::cout << "Running function estimateThresholds: ";
+        dev.check(dev.api->error_finalize(dev.ctx, &acc, C_value, cov, d_rate, d_code, nullptr, d_germ, d_gp, d_flags), "ampli_error_finalize");
+        std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
+        std::vector<uint8_t> code((size_t)P * 4), gp((size_t)P * 4);
+        int32_t flags = 0;
+        dev.download(rate.data(), d_rate, rate.size());
+        dev.download(code.data(), d_code, code.size());
+        dev.download(germ.data(), d_germ, germ.size());
+        dev.download(gp.data(), d_gp, gp.size());
+        dev.download(&flags, d_flags, 1);
+        dev.sync();
+        if (flags & 1) throw Error{AMPLI_E_ENVELOPE, "a double accumulator left the exactness envelope (see DESIGN.md); refusing to write an inexact table"};
+        double t3 = now_s();
+
+        char name[64];
+        snprintf(name, sizeof name, "positionSpecificNoise_%.4f.txt", (double)C_value); // EE:2556
+        const std::string out = a.output_dir + "/" + name;
+        write_error_table(panel, rate.data(), code.data(), germ.data(), gp.data(), out);
+        double t4 = now_s();
+        std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
+        if (getenv("AMPLISOLVE_TIMING"))
+            std::cerr << "TIMING panel " << t1 - t0 << "\nTIMING ingest " << t2 - t1 << " lines " << co.n_lines << "\nTIMING device " << t3 - t2
+                      << "\nTIMING write " << t4 - t3 << std::endl;
+        std::cout << "\n" << kLine << std::endl;
+        return 0;
+    } catch (const Error &e) {
+        std::cout << "\t\t\nSomething went wrong: " << e.msg << std::endl;
+        std::cout << "                                        Sorry but Amplisolve cannot continue..." << std::endl;
+        std::cout << kLine << std::endl;
+        return e.code ? e.code : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct CallRow {
+    int sample, line, alt;
+    int64_t rec;
+    double q_fw, q_bw;
+    float af, af_fw, af_bw;
+};
+
+} // namespace
+
+int run_variant_calling(const VcArgs &a)
+{
+    try {
+        float p_value = (float)std::atof(a.p_value.c_str()); // VC:262-294
+        int cov = std::atoi(a.coverage_cutoff.c_str());
+        std::cout << kLine << "\n" << std::endl;
+        std::cout << "                          AmpliSolve variant calling for batch execution of multiple samples\n" << std::endl;
+        std::cout << "                       MI355X-native build (amplisolve_amd); command line and files as AmpliSolveVariantCalling\n" << std::endl;
+        std::cout << "Execution started under the following parameters:" << std::endl;
+        std::cout << "\t1. Error estimation                               : " << a.error_file << std::endl;
+        std::cout << "\t2. Tumour count dir                               : " << a.tumour_dir << std::endl;
+        std::cout << "\t3. Output dir                                     : " << a.output_dir << std::endl;
+        if (cov <= 0) {
+            cov = 100;
+            std::cout << "\t4. Coverage cutoff                                  : User gave: " << a.coverage_cutoff << ". The value is converted to default 100" << std::endl;
+        } else {
+            std::cout << "\t4. Coverage cutoff                                : " << cov << std::endl;
+        }
+        if (p_value <= 0 || p_value > 1) {
+            p_value = 0.05f;
+            std::cout << "\t5. p-value                                         : User gave: " << a.p_value << ". The value is converted to default 0.05" << std::endl;
+        } else {
+            std::cout << "\t5. p-value                                        : " << p_value << std::endl;
+        }
+        std::cout << std::endl;
+
+        const std::string interm = a.output_dir + "/AmpliSolveVariantCalling_interm_files"; // VC:307
+        mkdir_p(interm);
+        Panel panel;
+        std::vector<float> thr;
+        panel_from_error_table(a.error_file, interm + "/dummyVCF_1.vcf", panel, thr); // VC:320
+        std::cout << "Running function storeInputFile: the error levels have stored with success " << panel.walk.size() << std::endl;
+        srand((unsigned)time(nullptr));
+        const int seed = rand() % 1000;
+        const std::string list_name = interm + "/" + std::to_string(seed) + "_tumour_count_list_original.txt"; // VC:332
+        Cohort co;
+        int threads = 0;
+        if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
+        cohort_load(panel, a.tumour_dir, list_name, threads, true, true, co);
+        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.S() << " samples" << std::endl;
+        std::cout << "\nRunning function callVariants...." << std::endl;
+
+        const int64_t P = co.P, R = co.R();
+        const int T = co.S();
+        std::vector<CallRow> rows;
+        {
+            Dev dev;
+            dev.open();
+            int32_t *d_recs = dev.upload(co.recs, (size_t)T * R * 8);
+            uint32_t *d_ext = co.E ? dev.upload(co.ext_pos.data(), co.ext_pos.size()) : nullptr;
+            float *d_thr = dev.upload(thr.data(), thr.size());
+            uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
+            uint8_t *d_mask = dev.alloc<uint8_t>((size_t)T * R);
+            unsigned long long *d_n = dev.alloc<unsigned long long>(1);
+            int64_t cap = std::max<int64_t>(1 << 16, (int64_t)T * R / 16);
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                ampli_call *d_calls = dev.alloc<ampli_call>((size_t)cap);
+                dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long)), "memset");
+                dev.check(dev.api->poisson_call(dev.ctx, d_recs, P, co.E, d_ext, T, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask,
+                                                d_calls, cap, d_n, nullptr, nullptr), "ampli_poisson_call");
+                unsigned long long n = 0;
+                dev.download(&n, d_n, 1);
+                dev.sync();
+                if ((int64_t)n > cap) { cap = (int64_t)n; continue; } // list overflowed: rerun with the exact size
+                std::vector<ampli_call> calls((size_t)n);
+                dev.download(calls.data(), d_calls, (size_t)n);
+                dev.sync();
+                rows.reserve(calls.size());
+                for (auto &c : calls)
+                    rows.push_back(CallRow{c.sample, co.line_no[(size_t)c.sample * R + c.record], c.alt, c.record, c.q_fw, c.q_bw, c.af, c.af_fw, c.af_bw});
+                break;
+            }
+        }
+        // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
+        std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
+            if (x.sample != y.sample) return x.sample < y.sample;
+            if (x.line != y.line) return x.line < y.line;
+            return x.alt < y.alt;
+        });
+
+        const std::string summary = a.output_dir + "/Summary_Variant_Info.txt"; // VC:342
+        std::ofstream output(summary);
+        output << "Filename\tChrom\tPosition\tSubtitution\tRD\tRD_fw\tRD_bw\tAF\tReads_fw\tReads_bw\tAF_fw\tAF_bw\tAmpliconEdge_StrandBias\tFisherPvalue\tQscore_fw\tQscore_bw\tReadTier\tGermlineInfo\tMaxGermlineAF\t10merDownstream\t10merUpstream\tHomopolymerFlag" << std::endl; // VC:669
+        size_t ri = 0;
+        for (int t = 0; t < T; ++t) {
+            std::ofstream vcf(a.output_dir + "/" + co.names[t] + ".vcf"); // VC:679
+            time_t now = time(0);
+            char *dt = ctime(&now);
+            vcf << "##fileformat=VCF-like\n##fileDate=" << dt
+                << "##source=AmpliSolveVariantCalling\n##reference=Not_Specified_here\n##phasing=Not_Specified_here\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##INFO=<ID=RD,Number=1,Type=Integer,Description='Total Read Depth'>\n##SAMPLE=<ID=Not_Specified_here,SampleName="
+                << co.names[t]
+                << ">\n##INFO=<ID=AF,Number=.,Type=Float,Description='Allele Frequency'>\n##INFO=<ID=SR,Number=1,Type=String,Description='Supporting Reads'>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"
+                << std::endl; // VC:688
+            if ((t + 1) % 50 == 0) std::cout << "\tParsed successfully " << t + 1 << "/" << T << "  samples" << std::endl;
+            for (; ri < rows.size() && rows[ri].sample == t; ++ri) {
+                const CallRow &c = rows[ri];
+                const int32_t *rec = co.recs + ((size_t)t * R + c.rec) * 8;
+                const int64_t p = c.rec < P ? c.rec : (int64_t)co.ext_pos[c.rec - P];
+                const std::string &chrom = panel.chroms[panel.pos_chrom[p]];
+                const int pos = panel.pos_coord[p];
+                const int FW = rec[0] + rec[1] + rec[2] + rec[3], BW = rec[4] + rec[5] + rec[6] + rec[7], RD = FW + BW;
+                const int alt_fw = rec[c.alt], alt_bw = rec[4 + c.alt];
+                const char refc = "ACGT"[panel.ref_code[p]], altc = "ACGT"[c.alt];
+                const std::string Flag_Dup = panel.dup[p] ? "YES" : "NO";
+                const double pf = fisher_two_sided(RD - BW, BW, alt_fw, alt_bw);      // VC:902
+                const std::string Flag_Fisher = pf <= p_value ? "YES" : "NO";         // VC:903-910
+                const std::string Flag_Tier = (alt_fw < 5 || alt_bw < 5) ? "LowQual" : "HighQual"; // VC:912-919
+                const std::string GermlineFlag = "-";                                 // VC:927-935 (map holds a dummy entry only)
+                const std::string MaxGermlineFlag = panel.germ_text[c.alt][p];        // VC:943-954
+                const std::string down = kmer_down(panel, chrom, pos), up = kmer_up(panel, chrom, pos);
+                const double Q = (c.q_fw + c.q_bw) / 2.000;                           // VC:968
+                const std::string cat = Flag_Dup + "_" + Flag_Fisher;
+                const double max_germ = std::atof(MaxGermlineFlag.c_str());           // VC:972
+                const int homo = homopolymer_test(down, up, altc);
+                // VC:993-1034: flags go through an unordered_map and come out in ITS order
+                std::unordered_map<std::string, std::string> Flag_Hash;
+                int OK = 0;
+                auto put = [&](const char *f) { OK = 1; Flag_Hash.insert(std::make_pair<std::string, std::string>(f, f)); };
+                if (cat == "YES_NO") put("AmpliconEdge");
+                if (cat == "YES_YES") put("AmpliconEdge;StrandBias");
+                if (cat == "NO_YES") put("StrandBias");
+                if (c.af < max_germ && cat == "NO_NO" && Flag_Tier != "HighQual") put("PositionWithHighNoise");
+                if (homo == 1) put("HomoPolymerRegion");
+                if (c.q_fw < 20 || c.q_bw < 20) put("LowQ");
+                if (Flag_Tier != "HighQual") put("LowSupportingReads");
+                std::string filter = "PASS";
+                if (OK) {
+                    filter.clear();
+                    for (auto it = Flag_Hash.begin(); it != Flag_Hash.end(); ++it) filter += (filter.empty() ? "" : ";") + it->first;
+                }
+                // the C->G block writes "-" instead of "." as ID when the call is not a PASS (VC:1856)
+                const char *id = (!OK || !(refc == 'C' && altc == 'G')) ? "." : "-";
+                vcf << chrom << "\t" << pos << "\t" << id << "\t" << refc << "\t" << altc << "\t" << Q << "\t" << filter << "\t" << c.af << ";" << RD
+                    << ";" << alt_fw + alt_bw << std::endl; // VC:1040 / 1062
+                // VC:1066 -- std::setprecision(4) is set mid-row and sticks for every later row of the file
+                output << co.names[t] << "\t" << chrom << "\t" << pos << "\t" << refc << "->" << altc << "\t" << RD << "\t" << FW << "\t" << BW << "\t"
+                       << c.af << "\t" << alt_fw << "\t" << alt_bw << "\t" << c.af_fw << "\t" << c.af_bw << "\t" << Flag_Dup << "_" << Flag_Fisher
+                       << "\t" << pf << "\t" << std::setprecision(4) << c.q_fw << "\t" << std::setprecision(4) << c.q_bw << "\t" << Flag_Tier << "\t"
+                       << GermlineFlag << "\t" << MaxGermlineFlag << "\t" << down << "\t" << up << "\t" << homo << std::endl;
+            }
+        }
+        output.close();
+        std::cout << "\nAmpliSolveVariantCalling execution was successful. The results can be found at : " << summary << std::endl;
+        std::cout << "\n" << kLine << std::endl;
+        return 0;
+    } catch (const Error &e) {
+        std::cout << "\t\t\nSomething went wrong: " << e.msg << std::endl;
+        std::cout << "                                        Sorry but Amplisolve cannot continue..." << std::endl;
+        std::cout << kLine << std::endl;
+        return e.code ? e.code : -1;
+    }
+}
+
+} // namespace ampli

@@ -1,0 +1,109 @@
+"""numpy views over the C++ host library's panel / cohort objects (include/amplisolve_host.h)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import AmpliError, host_lib
+
+
+def _b(s):
+    return s.encode() if isinstance(s, str) else s
+
+
+class HostCohort:
+    """BED (or error table) + a directory of .PILEUP.ASEQ files, packed by the C++ host."""
+
+    def __init__(self, bed_or_table, aseq_dir=None, refbases_file=None, fasta=None, is_error_table=False, threads=0,
+                 keep_line_no=False):
+        lib = host_lib()
+        h = C.c_void_p()
+        rc = lib.ampli_host_cohort_load(_b(bed_or_table), int(is_error_table), _b(refbases_file) if refbases_file else None,
+                                        _b(fasta) if fasta else None, _b(aseq_dir) if aseq_dir else None, threads,
+                                        int(keep_line_no), C.byref(h))
+        if rc != 0:
+            raise AmpliError(f"ampli_host_cohort_load: {lib.ampli_host_last_error().decode()}")
+        self._lib, self.h = lib, h
+        self.P = lib.ampli_host_cohort_P(h)
+        self.E = lib.ampli_host_cohort_E(h)
+        self.S = lib.ampli_host_cohort_S(h)
+        self.walk_len = lib.ampli_host_cohort_walk_len(h)
+        R = self.P + self.E
+
+        def arr(ptr, shape, dtype):
+            if not ptr or 0 in shape:
+                return np.zeros(shape, dtype)
+            n = int(np.prod(shape))
+            buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+        self.recs = arr(lib.ampli_host_cohort_recs(h), (self.S, R, 8), np.int32) if self.S else np.zeros((0, R, 8), np.int32)
+        self.dup_off = arr(lib.ampli_host_cohort_dup_off(h), (self.P + 1,), np.uint32) if self.S else np.zeros(self.P + 1, np.uint32)
+        self.ext_pos = arr(lib.ampli_host_cohort_ext_pos(h), (self.E,), np.uint32)
+        ln = lib.ampli_host_cohort_line_no(h)
+        self.line_no = arr(ln, (self.S, R), np.int32) if ln else None
+        self.ref_code = arr(lib.ampli_host_cohort_ref_code(h), (self.P,), np.uint8)
+        self.dup_flag = arr(lib.ampli_host_cohort_dup_flag(h), (self.P,), np.uint8)
+        self.names = [lib.ampli_host_cohort_sample_name(h, s).decode() for s in range(self.S)]
+
+    def stats(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._lib.ampli_host_cohort_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(lines=a.value, offpanel=b.value, irregular=c.value, malformed=d.value)
+
+    def position(self, p):
+        buf = C.create_string_buffer(256)
+        coord = C.c_int32()
+        self._lib.ampli_host_position(self.h, p, buf, 256, C.byref(coord))
+        return buf.value.decode(), coord.value
+
+    def write_error_table(self, rate, code, germ_val, germ_present, path):
+        rate = np.ascontiguousarray(rate, np.float32)
+        code = np.ascontiguousarray(code, np.uint8)
+        germ_val = np.ascontiguousarray(germ_val, np.float32)
+        germ_present = np.ascontiguousarray(germ_present, np.uint8)
+        rc = self._lib.ampli_host_write_error_table(self.h, rate.ctypes.data_as(C.c_void_p), code.ctypes.data_as(C.c_void_p),
+                                                    germ_val.ctypes.data_as(C.c_void_p), germ_present.ctypes.data_as(C.c_void_p), _b(path))
+        if rc != 0:
+            raise AmpliError(self._lib.ampli_host_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self._lib.ampli_host_cohort_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def read_error_table(path):
+    """-> (HostCohort-like panel object, thr [2,4,P] float32) as AmpliSolveVariantCalling would read it."""
+    lib = host_lib()
+    # first pass to learn P
+    h = C.c_void_p()
+    rc = lib.ampli_host_read_error_table(_b(path), C.byref(h), None, 0)
+    if rc != 0:
+        raise AmpliError(lib.ampli_host_last_error().decode())
+    P = lib.ampli_host_cohort_P(h)
+    lib.ampli_host_cohort_free(h)
+    thr = np.empty((2, 4, P), np.float32)
+    h = C.c_void_p()
+    rc = lib.ampli_host_read_error_table(_b(path), C.byref(h), thr.ctypes.data_as(C.c_void_p), thr.size)
+    if rc != 0:
+        raise AmpliError(lib.ampli_host_last_error().decode())
+    ref = np.frombuffer((C.c_char * P).from_address(lib.ampli_host_cohort_ref_code(h)), dtype=np.uint8).copy()
+    lib.ampli_host_cohort_free(h)
+    return ref, thr
+
+
+def sample_order(aseq_dir):
+    lib = host_lib()
+    buf = C.create_string_buffer(1 << 20)
+    n = lib.ampli_host_sample_order(_b(aseq_dir), buf, 1 << 20)
+    if n < 0:
+        raise AmpliError(lib.ampli_host_last_error().decode())
+    return buf.value.decode().split("\n")[:n]

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(ampli_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(ampli_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_hip_header_symbols_exported():

@@ -1,0 +1,80 @@
+"""Scalar helpers the kernels share with the host (csrc/ampli_math.h), checked on the CPU against the
+literal reference formulations in the oracle.  These pin the two transformations the kernels rely on:
+the integer AF gate and the integer text round trip; and the exact-decision bound of the prefilter."""
+import ctypes as C
+
+import numpy as np
+
+from amplisolve_amd import host_lib
+from oracle import pyoracle as orc
+
+
+def test_af_gate_integer_bound_equals_fp_gate():
+    """x <= floor(d * 26843545 / 2^29)  <=>  (double)((float)x/(float)d) <= 0.05   for 0 < d < 2^24."""
+    H, O = host_lib(), orc.lib()
+    rng = np.random.default_rng(0)
+    ds = np.unique(np.concatenate([np.arange(1, 6000), rng.integers(1, 1 << 24, 30000), [(1 << 24) - 1, 1 << 23, 12345678]]))
+    for d in ds:
+        d = int(d)
+        lim = H.ampli_host_af_limit(d)
+        # the bound is tight: lim passes, lim+1 fails; and it is monotone so nothing else needs checking
+        assert O.oracle_af_gate(lim, d) == 1, d
+        assert O.oracle_af_gate(lim + 1, d) == 0, d
+        assert abs(lim - 0.05 * d) <= 1
+    for d in (100, 101, 1999, 33395):  # exhaustive in x for a few depths
+        lim = H.ampli_host_af_limit(d)
+        for x in range(0, d + 1):
+            assert O.oracle_af_gate(x, d) == (1 if x <= lim else 0)
+
+
+def test_text_roundtrip_matches_sprintf_strtof():
+    H, O = host_lib(), orc.lib()
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([
+        rng.random(300000, dtype=np.float32) * np.float32(0.07),
+        rng.random(50000, dtype=np.float32) * np.float32(20),
+        (np.float32(10.0) ** rng.uniform(-14, 4, 50000)).astype(np.float32),
+        (np.arange(0, 70000, dtype=np.float64) * 1e-6 + 5e-7).astype(np.float32),        # decimal ties
+        (np.arange(0, 70000, dtype=np.float64) * 1e-6).astype(np.float32),                # exact 6-decimal values
+        np.array([0, -0.0, 1e-7, 4.9e-7, 5e-7, 5.1e-7, 1.5e-6, 0.002, 0.01, 0.05, 1, 15.999999, 16, 17.5, 1e6, 1e-45, 3e38, -0.0021], np.float32),
+    ]).astype(np.float32)
+    out = np.empty_like(vals)
+    H.ampli_host_text_roundtrip_batch(vals.ctypes.data_as(C.c_void_p), vals.size, out.ctypes.data_as(C.c_void_p))
+    exp = np.array([O.oracle_text_roundtrip(float(v)) for v in vals], np.float32)
+    assert np.array_equal(out.view(np.int32), exp.view(np.int32))
+    # every float in a dense window around typical rates (C = 0.002 .. 0.01)
+    lo = np.float32(0.0019).view(np.int32)
+    win = np.arange(lo, lo + 200000, dtype=np.int32).view(np.float32)
+    out = np.empty_like(win)
+    H.ampli_host_text_roundtrip_batch(win.ctypes.data_as(C.c_void_p), win.size, out.ctypes.data_as(C.c_void_p))
+    exp = np.array([O.oracle_text_roundtrip(float(v)) for v in win], np.float32)
+    assert np.array_equal(out.view(np.int32), exp.view(np.int32))
+
+
+def test_prefilter_bound_is_exact_decision():
+    """AMPLI_POISSON_PREFILTER skips a score when k <= m = RD*err.  That is only legal if the REFERENCE's scorer
+    (with its 99-step caps) returns Q < 5 there, so VC:898 is false anyway.  Sweep k <= m over five decades."""
+    H = host_lib()
+    rng = np.random.default_rng(4)
+    errs = np.array([0.0001, 0.0005, 0.001, 0.002, 0.002189, 0.0035, 0.01, 0.02, 0.05, 0.25, 0.0], np.float32)
+    ks, rds, es = [], [], []
+    for err in errs:
+        e = float(err) if err != 0 else float(np.float32(0.0010008))
+        rd = np.unique(np.concatenate([np.arange(1, 3000, 7), rng.integers(1, 1 << 24, 12000), np.geomspace(10, (1 << 24) - 1, 2000).astype(np.int64)]))
+        m = rd * e
+        for frac in (1.0, 0.999, 0.99, 0.9, 0.75, 0.5, 0.25, 0.1, 0.01):
+            for j in (0, 1, 2, 5):
+                k = np.floor(m * frac).astype(np.int64) - j
+                sel = k >= 1
+                ks.append(k[sel]); rds.append(rd[sel]); es.append(np.full(sel.sum(), err, np.float32))
+    k = np.concatenate(ks).astype(np.int32); rd = np.concatenate(rds).astype(np.int32); er = np.concatenate(es)
+    assert k.size > 500000
+    skip = np.array([H.ampli_host_prefilter_nocall(int(a), int(b), float(c)) for a, b, c in zip(k[::37], rd[::37], er[::37])])
+    assert skip.all()  # all of these have k <= m: the product would skip them
+    q, _ = orc.score_batch(k, rd, er)
+    assert not np.isnan(q).any()
+    assert q.max() < 5.0, (q.max(), k[q.argmax()], rd[q.argmax()], er[q.argmax()])
+    assert q.max() < 3.1  # P(X >= k) > 0.49 for k <= mean: Q stays near 3
+    # and the complement is not skipped
+    assert H.ampli_host_prefilter_nocall(3, 1000, 0.002) == 0 and H.ampli_host_prefilter_nocall(2, 1000, 0.002) == 1
+    assert H.ampli_host_prefilter_nocall(5, 1000, -1.0) == 1 and H.ampli_host_prefilter_nocall(0, 1000, 0.002) == 1

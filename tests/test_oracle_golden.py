@@ -1,0 +1,139 @@
+"""The CPU oracle (and the C++ host's parsers / writers) against the reference's own outputs.
+
+Fixtures under tests/golden/ were produced by tests/golden/make_golden.py from the compiled reference
+(oracle/_ref/ee_ref_driver, oracle/_ref/libvc_scorer_ref.so).  No GPU involved.
+"""
+import gzip
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from amplisolve_amd.hostio import HostCohort, read_error_table, sample_order
+from oracle import pyoracle as orc
+
+G = "/root/repo/tests/golden"  # literal: the sample visit order hashes the directory string
+pytestmark = pytest.mark.skipif(not os.path.isdir(G), reason="fixtures are addressed through the /root/repo path")
+
+
+def oracle_table(co, C, cov, tmp_path, name="t.txt"):
+    acc = orc.error_reduce(co.recs, co.P, C, cov, E=co.E, dup_off=co.dup_off)
+    assert acc["order_sensitive"] == 0
+    fin = orc.error_finalize(acc)
+    out = str(tmp_path / name)
+    co.write_error_table(fin["rate"], fin["code"], fin["germ_val"].astype(np.float32), fin["germ_present"], out)
+    return acc, fin, open(out).read()
+
+
+@pytest.mark.parametrize("C,cov,expected", [(0.002, 100, "expected_positionSpecificNoise_0.0020.txt"),
+                                            (0.01, 500, "expected_positionSpecificNoise_0.0100_cov500.txt")])
+def test_toy_subset_table_is_byte_identical(tmp_path, C, cov, expected):
+    d = f"{G}/toy_subset"
+    co = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
+    assert co.names == open(f"{d}/expected_visit_order.txt").read().split()
+    assert co.E > 0 and co.stats()["offpanel"] == 0
+    _, _, got = oracle_table(co, C, cov, tmp_path)
+    assert got == open(f"{d}/{expected}").read()
+
+
+def test_toy_subset_integer_counts_match_reference(tmp_path):
+    """Count_Hash of the reference (the integer quorum counts, EE:1665) == oracle cnt, key by key."""
+    d = f"{G}/toy_subset"
+    co = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
+    acc = orc.error_reduce(co.recs, co.P, 0.002, 100, E=co.E, dup_off=co.dup_off)
+    exp = dict(l.split() for l in open(f"{d}/expected_counts.txt"))
+    assert len(exp) == 4 * co.P
+    for p in range(co.P):
+        c, x = co.position(p)
+        for nt in range(4):
+            assert int(exp[f"{c}_{x}_{'ACGT'[nt]}"]) == acc["cnt"][nt, p]
+
+
+@pytest.mark.parametrize("tag,C,cov", [("0.0020_cov100", 0.002, 100), ("0.0005_cov1", 0.0005, 1), ("0.0500_cov1000", 0.05, 1000)])
+def test_mini_edge_table_is_byte_identical(tmp_path, tag, C, cov):
+    """Synthetic edge cases: absent lines, duplicated positions, FW or BW = 0 (NaN gate), depth around the cutoff,
+    AF around 5 %, quorum edges, chrX / chrM, N and soft-masked reference bases."""
+    d = f"{G}/mini_edge"
+    co = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
+    assert co.names == open(f"{d}/expected_visit_order.txt").read().split()
+    acc, fin, got = oracle_table(co, C, cov, tmp_path)
+    assert got == open(f"{d}/expected_positionSpecificNoise_{tag}.txt").read()
+    exp = dict(l.split() for l in open(f"{d}/expected_counts_{tag}.txt"))
+    for p in range(co.P):
+        c, x = co.position(p)
+        for nt in range(4):
+            assert int(exp[f"{c}_{x}_{'ACGT'[nt]}"]) == acc["cnt"][nt, p]
+    if cov <= 100:
+        assert set(np.unique(fin["code"])) >= {0, 1}
+
+
+def test_error_table_reader_round_trip(tmp_path):
+    """VC's storeInputFile view of a table == the oracle's finalize thr (text round trip, 0.01 substitution)."""
+    d = f"{G}/toy_subset"
+    co = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
+    acc, fin, _ = oracle_table(co, 0.002, 100, tmp_path, "rt.txt")
+    ref, thr = read_error_table(str(tmp_path / "rt.txt"))
+    assert np.array_equal(ref, co.ref_code)
+    for nt in range(4):
+        m = co.ref_code != nt  # the ref cell is "-2_-2", never read by the caller
+        assert np.array_equal(thr[:, nt][:, m].view(np.int32), fin["thr"][:, nt][:, m].view(np.int32))
+        assert (thr[:, nt][:, ~m] == -2).all()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Toy_data"), reason="full Toy_data only exists in the build container")
+def test_full_toy_data_digest(tmp_path):
+    """Config 1 of BASELINE.json: the whole Toy_data panel, digest of the reference's table."""
+    T = "/root/reference/Toy_data"
+    refb = tmp_path / "refbases.txt"
+    refb.write_bytes(gzip.open(f"{G}/toy/refbases.txt.gz").read())
+    co = HostCohort(f"{T}/AmpliSeq_30genes_Designed-1.bed", f"{T}/NORMAL_ASEQ_DIR", refbases_file=str(refb))
+    assert co.names == open(f"{G}/toy/visit_order.txt").read().split()
+    assert (co.P, co.walk_len, co.S) == (40814, 41486, 5)
+    _, _, got = oracle_table(co, 0.002, 100, tmp_path)
+    want = open(f"{G}/toy/digests.txt").read().split()[2]
+    assert hashlib.sha256(got.encode()).hexdigest() == want == "ebb19204f4d1ca3020be3ee8b7457564c817f64c88166b11aa0f847ed826ba3a"
+    assert got == gzip.open(f"{G}/toy/positionSpecificNoise_0.0020.txt.gz").read().decode()
+    assert sample_order(f"{T}/TUMOUR_ASEQ_DIR") == ["T3", "T2", "T1"]
+
+
+def test_scorer_against_reference_grid():
+    z = np.load(f"{G}/vc_scorer_reference.npz")
+    q, _ = orc.score_batch(z["k"], z["rd"], z["err"])
+    assert np.array_equal(q.view(np.int64), z["q"].view(np.int64))  # bit for bit, incl. -888 / 100 / 0 specials
+    L = orc.lib()
+    gq = np.array([L.oracle_kf_gammaq(float(a), float(b)) for a, b in zip(z["s"], z["z"])])
+    assert np.array_equal(gq.view(np.int64), z["gammaq"].view(np.int64))
+    lg = np.array([L.oracle_kf_lgamma(float(a)) for a in z["s"]])
+    assert np.array_equal(lg.view(np.int64), z["lgamma"].view(np.int64))
+
+
+def test_scorer_known_answers_from_survey():
+    """values the surveyor captured from the compiled reference."""
+    L = orc.lib()
+    f = float(np.float32(0.002))
+    for s, zz, want in [(1, 1000 * f, 0.13533527038045126), (2, 1000 * f, 0.40600582399751517), (3, 1000 * f, 0.67667639047073891),
+                        (5, 1000 * f, 0.94734697408551383), (8, 1000 * f, 0.99890328070563561), (40, 25000 * f, 0.064570328074039979)]:
+        assert L.oracle_kf_gammaq(float(s), zz) == want
+    for k, rd, e, want in [(0, 1000, 0.002, 0.0), (1, 1000, 0.002, 0.63152255889662207), (2, 1000, 0.002, 2.2621781317096674),
+                           (3, 1000, 0.002, 4.9036258145739694), (5, 1000, 0.002, 12.785766653103605), (8, 1000, 0.002, 29.599045160064782),
+                           (20, 1000, 0.002, 100.0), (250, 25000, 0.002, 100.0), (1, 100, 0.01, 1.9920009027716749),
+                           (40, 25000, 0.002, 0.28988858343132076), (3, 1000, -1.0, -888.0), (3, 1000, 0.0, 10.944814144876279)]:
+        assert float(L.oracle_score(k, rd, e)) == pytest.approx(want, rel=1e-15, abs=0)
+
+
+@pytest.mark.skipif(not os.path.exists(orc.REF_VC_SCORER), reason="reference scorer build not present")
+def test_scorer_bitwise_vs_reference_random():
+    import ctypes as C
+
+    R = C.CDLL(orc.REF_VC_SCORER)
+    rng = np.random.default_rng(2)
+    n = 500000
+    k = rng.integers(0, 500, n).astype(np.int32)
+    rd = rng.integers(0, 60000, n).astype(np.int32)
+    err = rng.choice(np.array([0.002, 0.01, 0.0005, 0.05, 0.0, -1.0, 0.002189, 0.000123, 0.3], np.float32), n)
+    want = np.empty(n)
+    R.ref_score_batch(k.ctypes.data_as(C.c_void_p), rd.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p), C.c_long(n),
+                      want.ctypes.data_as(C.c_void_p))
+    got, _ = orc.score_batch(k, rd, err)
+    assert np.array_equal(got.view(np.int64), want.view(np.int64))
