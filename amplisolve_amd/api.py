@@ -23,16 +23,25 @@ def _ptr(t):
 class Acc:
     """Accumulator table (ampli_acc_table) living in one device buffer."""
 
-    def __init__(self, ctx: "Context", P: int, buf=None):
+    def __init__(self, ctx: "Context | None", P: int, buf=None, device=None):
+        """ctx may be None for a host-side table (layout functions need no GPU): pass device="cpu"."""
         import torch
 
-        lib = ctx.lib
+        lib = ctx.lib if ctx is not None else hip_lib()
         self.P = int(P)
         nbytes = lib.ampli_acc_bytes(self.P)
-        self.buf = buf if buf is not None else torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)
+        dev = device if device is not None else ctx.device
+        if buf is None:
+            # over-allocate on the host so the base can be 256-byte aligned like a device allocation
+            raw = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            off = (-raw.data_ptr()) % 256
+            buf = raw[off: off + nbytes]
+        self.buf = buf
         assert self.buf.numel() >= nbytes and self.buf.data_ptr() % 256 == 0
         self.struct = AccTable()
-        ctx._check(lib.ampli_acc_bind(_ptr(self.buf), self.P, C.byref(self.struct)))
+        rc = lib.ampli_acc_bind(_ptr(self.buf), self.P, C.byref(self.struct))
+        if rc != 0:
+            raise AmpliError("ampli_acc_bind failed")
         base = self.buf.data_ptr()
 
         def view(ptr, dtype, shape):

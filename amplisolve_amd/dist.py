@@ -4,12 +4,16 @@ The path shards naturally: tumour samples are independent given
 the error table, and the normal panel shards by contiguous sample ranges.  The
 only exchange step is the merge of the per-position accumulator table:
 
-  * planes that merge by addition (snt f64, srd i64, cnt/nrec/gm_n i32) -> all-reduce SUM per dtype
+  * planes that merge by addition (snt f64, srd i64, cnt/nrec i32) -> all-reduce SUM per dtype
     (the double sums are exact inside the envelope, so the reduction order is immaterial);
   * the germ-max triple is order dependent -> all-gather of the gm region + ordered fold on every rank
     (ampli_gm_merge), which reproduces the reference's sequential state machine bit for bit.
+
+The same function runs over gloo on CPU tensors (tests, world_size 2) with a host-side fold.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 
 def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
@@ -19,24 +23,35 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def merge_error_table(ctx, acc, group=None, gather_buf=None):
-    """In-place merge of every rank's partial table `acc` (rank order = sample order)."""
+def table_regions(P: int):
+    """(sum_bytes, gm_offset, gm_bytes) of an accumulator-table buffer (ampli_acc_regions; needs no GPU)."""
+    from ._lib import hip_lib
+
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    if hip_lib().ampli_acc_regions(P, C.byref(a), C.byref(b), C.byref(c)) != 0:
+        raise ValueError("ampli_acc_regions failed")
+    return a.value, b.value, c.value
+
+
+def merge_error_table(acc, fold, group=None, gather_buf=None):
+    """In-place merge of every rank's partial table `acc` (an api.Acc; rank order = sample order).
+
+    fold(acc, gathered_regions, world) folds the gathered germ-max regions into acc's gm planes:
+    Context.gm_merge on the GPU, a host fold in the CPU tests."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     if world == 1:
         return acc
-    sum_bytes, gm_off, gm_bytes = ctx.regions(acc.P)
+    _, gm_off, gm_bytes = table_regions(acc.P)
     region = acc.buf[gm_off: gm_off + gm_bytes]
     if gather_buf is None:
         gather_buf = torch.empty(world * gm_bytes, dtype=torch.uint8, device=acc.buf.device)
-    # gm region first: it contains the per-shard gm_n the fold needs
-    w_g = dist.all_gather_into_tensor(gather_buf, region, group=group, async_op=True)
-    w_g.wait()
-    works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)
-             for t in (acc.snt, acc.srd, acc.cnt, acc.nrec)]
-    for w in works:
+    # the gm region goes first: it carries the per-shard gm_n the fold needs
+    work = [dist.all_gather_into_tensor(gather_buf, region, group=group, async_op=True)]
+    work += [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True) for t in (acc.snt, acc.srd, acc.cnt, acc.nrec)]
+    for w in work:
         w.wait()
-    ctx.gm_merge(acc, gather_buf, world)
+    fold(acc, gather_buf, world)
     return acc

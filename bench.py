@@ -197,7 +197,7 @@ def main():
         if i is not None:
             ctx.record(ev[i][1])
         if world > 1:
-            merge_error_table(ctx, acc, gather_buf=gather_buf)
+            merge_error_table(acc, ctx.gm_merge, gather_buf=gather_buf)
         fin = ctx.error_finalize(acc, 0.002, 100, out=fin)
         n_calls.zero_()
         if i is not None:

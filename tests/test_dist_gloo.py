@@ -1,0 +1,101 @@
+"""The multi-rank merge protocol (amplisolve_amd/dist.py) over gloo, world_size 2, on CPU.
+
+Each rank reduces its contiguous shard of the normal samples (here with the oracle, since there is no GPU),
+then the ranks merge exactly as bench.py does over RCCL: all-reduce SUM of the additive planes, all-gather
+of the germ-max regions, ordered fold.  Result must equal the single-pass table bit for bit on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from amplisolve_amd.api import Acc
+from amplisolve_amd.dist import merge_error_table, shard_range, table_regions
+from oracle import pyoracle as orc
+from tests.helpers import synth_recs
+
+P, S = 1500, 23
+
+
+def host_fold(acc, gathered, world):
+    """numpy twin of ampli_gm_merge (csrc/ampli_kernels.hip gm_merge_kernel)."""
+    _, gm_off, gm_bytes = table_regions(acc.P)
+    n4 = 4 * acc.P
+    offs = [acc.struct.gm_n - acc.struct.gm_n, acc.struct.gm_first - acc.struct.gm_n, acc.struct.gm_first_af - acc.struct.gm_n,
+            acc.struct.gm_rest - acc.struct.gm_n]
+    g = gathered.numpy().reshape(world, gm_bytes)
+    n = np.zeros(n4, np.int32); first = np.full(n4, 0x7fffffff, np.int32)
+    faf = np.zeros(n4, np.float32); rest = np.full(n4, -np.inf, np.float32)
+    for k in range(world):
+        rn = g[k, offs[0]: offs[0] + 4 * n4].view(np.int32)
+        rf = g[k, offs[1]: offs[1] + 4 * n4].view(np.int32)
+        ra = g[k, offs[2]: offs[2] + 4 * n4].view(np.float32)
+        rr = g[k, offs[3]: offs[3] + 4 * n4].view(np.float32)
+        has, empty = rn > 0, n == 0
+        take = has & empty
+        first[take], faf[take], rest[take] = rf[take], ra[take], rr[take]
+        fold = has & ~empty
+        rest[fold] = np.maximum(rest[fold], np.maximum(ra[fold], rr[fold]))
+        n = n + rn
+    acc.gm_n.copy_(torch.from_numpy(n.reshape(4, acc.P)))
+    acc.gm_first.copy_(torch.from_numpy(first.reshape(4, acc.P)))
+    acc.gm_first_af.copy_(torch.from_numpy(faf.reshape(4, acc.P)))
+    acc.gm_rest.copy_(torch.from_numpy(rest.reshape(4, acc.P)))
+
+
+def worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        recs = synth_recs(P, S)
+        lo, hi = shard_range(S, rank, world)
+        part = orc.error_reduce(recs[lo:hi], P, 0.002, 100, first_sample=lo)
+        acc = Acc(None, P, device="cpu")
+        acc.buf.zero_()
+        for name in ("snt", "srd", "cnt", "nrec", "gm_n", "gm_first", "gm_first_af", "gm_rest"):
+            getattr(acc, name).copy_(torch.from_numpy(part[name]))
+        merge_error_table(acc, host_fold)
+        full = orc.error_reduce(recs, P, 0.002, 100)
+        ok = True
+        for name in ("snt", "srd", "cnt", "nrec", "gm_n"):
+            ok &= bool(np.array_equal(getattr(acc, name).numpy(), full[name]))
+        m1, m2 = full["gm_n"] > 0, full["gm_n"] > 1
+        ok &= bool(np.array_equal(acc.gm_first.numpy()[m1], full["gm_first"][m1]))
+        ok &= bool(np.array_equal(acc.gm_first_af.numpy()[m1].view(np.int32), full["gm_first_af"][m1].view(np.int32)))
+        ok &= bool(np.array_equal(acc.gm_rest.numpy()[m2].view(np.int32), full["gm_rest"][m2].view(np.int32)))
+        fin_a = orc.error_finalize({k: getattr(acc, k).numpy() for k in ("snt", "srd", "cnt", "nrec", "gm_n", "gm_rest")})
+        fin_b = orc.error_finalize(full)
+        ok &= all(np.array_equal(fin_a[k], fin_b[k], equal_nan=True) for k in fin_a)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 96, 1024):
+        for w in (1, 2, 3, 8):
+            cuts = [shard_range(n, r, w) for r in range(w)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_merge_protocol_over_gloo(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(r for r, _ in res) == list(range(world))
+    assert all(ok for _, ok in res)
