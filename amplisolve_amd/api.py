@@ -113,8 +113,14 @@ class Context:
     def sync(self):
         self._check(self.lib.ampli_sync(self.h))
 
-    def set_tuning(self, reduce_splits: int = 0):
-        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, 0))
+    def set_tuning(self, reduce_splits: int = 0, general: bool = False):
+        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general)))
+
+    def flags(self, clear: bool = True) -> int:
+        """AMPLI_FLAG_* raised by kernels since the last clear (synchronises)."""
+        out = C.c_int32()
+        self._check(self.lib.ampli_ctx_flags(self.h, C.byref(out), int(clear)))
+        return int(out.value)
 
     # ---- events on the context's stream -------------------------------------------------
     def event(self):

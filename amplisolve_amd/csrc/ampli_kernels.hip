@@ -29,6 +29,8 @@ struct ampli_ctx {
     void *ws = nullptr; // workspace for partial accumulator tables
     size_t ws_bytes = 0;
     int reduce_splits = 0; // 0 = auto
+    int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
+    int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
     int n_cu = 256;
 };
 
@@ -89,6 +91,11 @@ extern "C" int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **ou
     } else {
         ctx->stream = (hipStream_t)stream; // NULL = the device's default (null) stream
     }
+    if (hipMalloc((void **)&ctx->d_flags, 256) != hipSuccess || hipMemset(ctx->d_flags, 0, 256) != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return AMPLI_E_NOMEM;
+    }
     *out = ctx;
     return AMPLI_OK;
 }
@@ -98,6 +105,7 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -172,10 +180,20 @@ extern "C" int ampli_event_elapsed_ms(void *a, void *b, float *ms)
     return hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP;
 }
 
-extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t)
+extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general)
 {
     if (!ctx || reduce_sample_splits < 0) return AMPLI_E_INVALID;
     ctx->reduce_splits = reduce_sample_splits;
+    ctx->reduce_general = reduce_general ? 1 : 0;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear)
+{
+    if (!ctx || !out) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (clear) HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(int), ctx->stream));
     return AMPLI_OK;
 }
 
@@ -377,6 +395,91 @@ __device__ __forceinline__ void lane_acc_load(const AccPtrs &t, long long P, lon
 }
 
 // ---------------------------------------------------------------------------
+// Fast per-lane state (the shipped inner loop).  Same results as LaneAcc /
+// visit_record, fewer instructions per record:
+//   * the qualifying sums are kept as an integer part (sum of X, sum of depth,
+//     int32: a wave never sees more than 64 samples) and a double part (sum of
+//     the fp32 products); snt = (double)sumX + sumP is exact inside the
+//     envelope of DESIGN.md section 4, like every other association;
+//   * Germ_Max needs max over records of RN(x/d); RN is monotone, so the
+//     argmax of the exact fraction is tracked by cross-multiplication (two
+//     24-bit multiplies per side) and ONE division per lane is done at the end
+//     instead of one IEEE fp32 division per record and nucleotide.
+// Valid while every depth is < 2^22 (FAST_COUNT_LIMIT): beyond that a lane
+// raises AMPLI_FLAG_RERUN_GENERAL and the caller reruns the literal kernel.
+// ---------------------------------------------------------------------------
+constexpr int FAST_COUNT_LIMIT = 1 << 22;
+constexpr int FAST_MAX_CHUNK = 64;        // samples per wave (int32 sums: 64 x (1+extras) x 2^22 < 2^31 for <= 7 extras)
+constexpr int FAST_MAX_RECORDS = 511;     // records per wave and position before the int32 sums could wrap
+
+struct FastAcc {
+    int sx[2][4];     // sum of X over qualifying records
+    int sd[2][4];     // sum of strand depth over qualifying records
+    double sp[2][4];  // sum of float(depth)*float(C) over qualifying records
+    int cnt[4];
+    int nrec;
+    int gn[4], gfx[4], gfd[4], gfi[4]; // germ-max: qualifying count; first record as a fraction + its sample index
+    int gbx[4], gbd[4];                // best later record as a fraction (0/1 until one exists)
+    int bad;                           // a depth beyond FAST_COUNT_LIMIT was seen
+};
+
+__device__ __forceinline__ void fast_init(FastAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        a.sx[0][nt] = a.sx[1][nt] = 0;
+        a.sd[0][nt] = a.sd[1][nt] = 0;
+        a.sp[0][nt] = a.sp[1][nt] = 0.0;
+        a.cnt[nt] = 0;
+        a.gn[nt] = 0; a.gfx[nt] = 0; a.gfd[nt] = 1; a.gfi[nt] = 0x7fffffff;
+        a.gbx[nt] = 0; a.gbd[nt] = 1;
+    }
+    a.nrec = 0;
+    a.bad = 0;
+}
+
+// 48-bit product of two values known to be < 2^24 (v_mul_u32_u24 + v_mul_hi_u32_u24, both full rate)
+__device__ __forceinline__ unsigned long long mul24x24(int a, int b)
+{
+    return (unsigned long long)((unsigned)a & 0xFFFFFFu) * (unsigned long long)((unsigned)b & 0xFFFFFFu);
+}
+
+__device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4 r1, const int sample, const float C,
+                                           const int cov)
+{
+    const bool present = r0.x != AMPLI_ABSENT;
+    const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
+    const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
+    const int FW = fw[0] + fw[1] + fw[2] + fw[3];  // EE:1175
+    const int BW = bw[0] + bw[1] + bw[2] + bw[3];  // EE:1176
+    const int RD = FW + BW;
+    const bool covok = present && FW >= cov && BW >= cov; // EE:1595, EE:1251
+    a.nrec += present ? 1 : 0;                     // EE:1659
+    if (!__any(covok)) return;
+    a.bad |= (covok && (unsigned)RD >= (unsigned)FAST_COUNT_LIMIT) ? 1 : 0;
+    const int lim_fw = ampli_af_limit(FW), lim_bw = ampli_af_limit(BW), lim_rd = ampli_af_limit(RD);
+    const double prod_fw = (double)((float)FW * C); // EE:1597
+    const double prod_bw = (double)((float)BW * C); // EE:1599
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
+            a.sx[0][nt] += fw[nt]; a.sd[0][nt] += FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
+            a.sx[1][nt] += bw[nt]; a.sd[1][nt] += BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
+            a.cnt[nt] += 1;                                                   // EE:1606
+        }
+        const int x = fw[nt] + bw[nt];
+        if (covok && x <= lim_rd) { // EE:1251: float(X)/float(RD) <= 0.05
+            if (a.gn[nt] == 0) {    // first qualifying record: its AF is dropped by the reference (EE:1258-1261)
+                a.gfx[nt] = x; a.gfd[nt] = RD; a.gfi[nt] = sample;
+            } else if (mul24x24(x, a.gbd[nt]) > mul24x24(a.gbx[nt], RD)) { // x/RD > best: EE:1266 (ties keep the value)
+                a.gbx[nt] = x; a.gbd[nt] = RD;
+            }
+            a.gn[nt] += 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // error_reduce: workgroup = 4 waves x 64 positions.  Wave w of workgroup
 // (tile, split) owns the contiguous sample chunk c = split*4 + w and streams
 // its 64 positions' 32-byte records (2 KiB contiguous per sample row, two
@@ -387,6 +490,24 @@ __device__ __forceinline__ void lane_acc_load(const AccPtrs &t, long long P, lon
 constexpr int RED_WAVES = 4;
 constexpr int RED_UNROLL = 2;
 
+__device__ __forceinline__ void fast_to_lane(const FastAcc &f, LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            a.snt[st][nt] = (double)f.sx[st][nt] + f.sp[st][nt];
+            a.srd[st][nt] = (long long)f.sd[st][nt];
+        }
+        a.cnt[nt] = f.cnt[nt];
+        a.gm_n[nt] = f.gn[nt];
+        a.gm_first[nt] = f.gfi[nt];
+        a.gm_first_af[nt] = f.gn[nt] > 0 ? (float)f.gfx[nt] / (float)f.gfd[nt] : 0.0f; // EE:1229-1232
+        a.gm_rest[nt] = f.gn[nt] > 1 ? (float)f.gbx[nt] / (float)f.gbd[nt] : -INFINITY;
+    }
+    a.nrec = f.nrec;
+}
+
 struct RedShared {
     double snt[RED_WAVES - 1][8][64];
     long long srd[RED_WAVES - 1][8][64];
@@ -394,11 +515,12 @@ struct RedShared {
     float flts[RED_WAVES - 1][8][64];
 };
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void error_reduce_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
     const size_t part_stride, const size_t o0, const size_t o1, const size_t o2, const size_t o3, const size_t o4,
-    const size_t o5, const size_t o6, const size_t o7)
+    const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags)
 {
     __shared__ RedShared sh;
     const int lane = threadIdx.x & 63;
@@ -412,7 +534,9 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     const int s1 = min(S, s0 + chunk_len);
 
     LaneAcc a;
-    lane_acc_init(a);
+    FastAcc f;
+    if (FAST) fast_init(f);
+    else lane_acc_init(a);
 
     unsigned e0 = 0, e1 = 0;
     if (E > 0) { e0 = dup_off[p]; e1 = dup_off[p + 1]; }
@@ -444,15 +568,21 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
 #pragma unroll
         for (int u = 0; u < RED_UNROLL; ++u) {
             if (s + u < s1) {
-                visit_record(a, c0[u], c1[u], first_sample + s + u, C, cov);
+                if (FAST) visit_fast(f, c0[u], c1[u], first_sample + s + u, C, cov);
+                else visit_record(a, c0[u], c1[u], first_sample + s + u, C, cov);
                 if (any_dup) { // extras of this position in the same sample, in file order
                     for (unsigned e = e0; e < e1; ++e) {
                         const int4 *q = recs + ((size_t)(s + u) * R + (size_t)P + e) * 2;
-                        visit_record(a, q[0], q[1], first_sample + s + u, C, cov);
+                        if (FAST) visit_fast(f, q[0], q[1], first_sample + s + u, C, cov);
+                        else visit_record(a, q[0], q[1], first_sample + s + u, C, cov);
                     }
                 }
             }
         }
+    }
+    if (FAST) {
+        if (f.bad || f.nrec > FAST_MAX_RECORDS) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
+        fast_to_lane(f, a);
     }
 
     // ordered combine of the 4 wave partials through LDS (wave order = sample order)
@@ -931,6 +1061,11 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
         if (splits < 1) splits = 1;
     }
     if (splits > S) splits = S;
+    const bool fast = !ctx->reduce_general;
+    if (fast) { // int32 partial sums: a wave takes at most FAST_MAX_CHUNK samples
+        const int need = (S + RED_WAVES * FAST_MAX_CHUNK - 1) / (RED_WAVES * FAST_MAX_CHUNK);
+        if (splits < need) splits = need;
+    }
     const int chunks = splits * RED_WAVES;
     const int chunk_len = (S + chunks - 1) / chunks;
 
@@ -945,9 +1080,14 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
         stride = off[8];
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
-    hipLaunchKernelGGL(error_reduce_kernel, grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, (long long)E,
-                       d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0], off[1], off[2],
-                       off[3], off[4], off[5], off[6], off[7]);
+    if (fast)
+        hipLaunchKernelGGL(error_reduce_kernel<true>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P,
+                           (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],
+                           off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags);
+    else
+        hipLaunchKernelGGL(error_reduce_kernel<false>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P,
+                           (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],
+                           off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags);
     int rc = check_launch(ctx, "error_reduce_kernel");
     if (rc) return rc;
     if (splits > 1) {

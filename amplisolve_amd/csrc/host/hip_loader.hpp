@@ -29,6 +29,8 @@ struct HipApi {
                         const ampli_acc_table *);
     int (*error_finalize)(ampli_ctx *, const ampli_acc_table *, float, int32_t, float *, uint8_t *, float *, float *, uint8_t *,
                           int32_t *);
+    int (*set_tuning)(ampli_ctx *, int32_t, int32_t);
+    int (*ctx_flags)(ampli_ctx *, int32_t *, int32_t);
     int (*poisson_call)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, const float *,
                         const uint8_t *, int32_t, int32_t, uint8_t *, ampli_call *, int64_t, unsigned long long *, double *,
                         float *);

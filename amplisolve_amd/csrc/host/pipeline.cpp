@@ -173,6 +173,12 @@ int run_error_estimation(const EeArgs &a)
         int32_t *d_flags = dev.alloc<int32_t>(1);
         dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
         dev.check(dev.api->error_reduce(dev.ctx, d_recs, P, co.E, d_dup, co.S(), 0, C_value, cov, &acc), "ampli_error_reduce");
+        int32_t kflags = 0;
+        dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+        if (kflags & AMPLI_FLAG_RERUN_GENERAL) { // a depth beyond the fast kernel's integer envelope: literal kernel
+            dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning");
+            dev.check(dev.api->error_reduce(dev.ctx, d_recs, P, co.E, d_dup, co.S(), 0, C_value, cov, &acc), "ampli_error_reduce");
+        }
         std::cout << "Running function estimateThresholds: ";
         dev.check(dev.api->error_finalize(dev.ctx, &acc, C_value, cov, d_rate, d_code, nullptr, d_germ, d_gp, d_flags), "ampli_error_finalize");
         std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);

@@ -215,8 +215,14 @@ int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int32_t n_sampl
                      int32_t first_sample, uint64_t seed, int32_t depth, int32_t tumour);
 int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t seed);
 
-/* tuning knobs (0 = automatic): waves are fixed at 4 per workgroup */
-int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reserved);
+/* tuning knobs.  reduce_sample_splits: 0 = automatic.  reduce_general: 0 = the fast error_reduce kernel
+ * (valid while every strand depth is < 2^22; it raises AMPLI_FLAG_RERUN_GENERAL otherwise), 1 = the literal
+ * kernel that follows the reference operation by operation for any depth (slower). */
+int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general);
+
+/* Flags raised by kernels of this context since the last clear (synchronises the stream). */
+#define AMPLI_FLAG_RERUN_GENERAL 2 /* error_reduce met a depth >= 2^22: its table is invalid, rerun with reduce_general = 1 */
+int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear);
 
 #ifdef __cplusplus
 }

@@ -67,15 +67,51 @@ def test_error_reduce_synthetic(ctx, P, S, splits):
     assert int(fin.flags.item()) == 0
 
 
+@pytest.mark.parametrize("general", [False, True])
 @pytest.mark.parametrize("C,cov", [(0.002, 100), (0.01, 50), (0.0005, 1), (0.002, 1000)])
-def test_error_reduce_edge_cases(ctx, C, cov):
+def test_error_reduce_edge_cases(ctx, C, cov, general):
     rng = np.random.default_rng(7)
     P, S = 517, 41
     recs = edge_case_recs(P, S, rng)
     ref = orc.error_reduce(recs, P, C, cov)
+    ctx.set_tuning(0, general=general)
     acc = ctx.error_reduce(_t(recs), P, C, cov)
+    ctx.set_tuning(0)
+    assert ctx.flags() == 0
     assert_acc_equal(acc, ref)
     assert_final_equal(ctx.error_finalize(acc, C, cov), orc.error_finalize(ref))
+
+
+@pytest.mark.parametrize("P,S,splits", [(65, 5, 2), (1000, 33, 3), (4097, 200, 0)])
+def test_error_reduce_general_kernel_synthetic(ctx, P, S, splits):
+    """The literal kernel (reference operation order, any depth) and the fast kernel agree with the oracle."""
+    recs = synth_recs(P, S)
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    for general in (True, False):
+        ctx.set_tuning(splits, general=general)
+        acc = ctx.error_reduce(_t(recs), P, 0.002, 100)
+        ctx.set_tuning(0)
+        assert_acc_equal(acc, ref)
+
+
+def test_fast_kernel_flags_depths_beyond_its_envelope(ctx):
+    """Depths >= 2^22 are outside the fast kernel's integer envelope: it must say so, and the literal kernel
+    (incl. the fp32 AF gate above 2^24 reads) must still match the oracle."""
+    rng = np.random.default_rng(21)
+    P, S = 200, 9
+    recs = synth_recs(P, S)
+    recs[3, 17] = [5_000_000, 40_000, 7, 0, 4_900_000, 38_000, 0, 9]          # > 2^22
+    recs[5, 99] = [20_000_000, 900_000, 3, 1, 19_000_000, 800_000, 2, 0]      # > 2^24: float(x) is no longer exact
+    recs[6, 99] = [20_000_001, 1_000_003, 3, 1, 19_000_001, 950_001, 2, 0]
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    ctx.flags()
+    ctx.error_reduce(_t(recs), P, 0.002, 100)
+    assert ctx.flags() & 2
+    ctx.set_tuning(0, general=True)
+    acc = ctx.error_reduce(_t(recs), P, 0.002, 100)
+    ctx.set_tuning(0)
+    assert ctx.flags() == 0
+    assert_acc_equal(acc, ref)
 
 
 def test_error_reduce_all_absent_and_empty_quorum(ctx):

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per kernel per dispatch."""
+import csv, sys, collections, glob
+for path in sys.argv[1:]:
+    for f in glob.glob(path + "/*/*_counter_collection.csv"):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0][:40]
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, d in acc.items():
+            if not any(x in k for x in ("error_reduce", "poisson_call", "finalize", "acc_merge")):
+                continue
+            print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
