@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(PKG, "lib", "libamplisolve_hip.so")
+HIP_LIB_PATH = os.environ.get("AMPLISOLVE_HIP_LIB") or os.path.join(PKG, "lib", "libamplisolve_hip.so")
 HOST_LIB_PATH = os.path.join(PKG, "lib", "libamplisolve_host.so")
 
 vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -66,6 +66,7 @@ HIP_SYMBOLS = {
     "ampli_synth_ref": (C.c_int, [vp, vp, i64, u64]),
     "ampli_set_tuning": (C.c_int, [vp, i32, i32]),
     "ampli_ctx_flags": (C.c_int, [vp, C.POINTER(i32), i32]),
+    "ampli_set_queue_items": (C.c_int, [vp, i64]),
 }
 
 HOST_SYMBOLS = {
@@ -74,6 +75,7 @@ HOST_SYMBOLS = {
     "ampli_host_text_roundtrip_batch": (None, [vp, i64, vp]),
     "ampli_host_af_limit": (i32, [i32]),
     "ampli_host_prefilter_nocall": (C.c_int, [i32, i32, f32]),
+    "ampli_host_prefilter_skip_f32": (C.c_int, [i32, i32, f32]),
     "ampli_host_last_error": (C.c_char_p, []),
     "ampli_host_cohort_load": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
     "ampli_host_cohort_free": (None, [vp]),

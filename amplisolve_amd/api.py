@@ -14,6 +14,9 @@ from ._lib import AccTable, AmpliError, Call, hip_lib
 NT = "ACGT"
 POISSON_FULL = 0
 POISSON_PREFILTER = 1
+CALL_SHARDS = 32            # AMPLI_CALL_SHARDS
+CALL_COUNTER_STRIDE = 16    # AMPLI_CALL_COUNTER_STRIDE
+CALL_COUNTER_WORDS = CALL_SHARDS * CALL_COUNTER_STRIDE
 
 
 def _ptr(t):
@@ -116,6 +119,9 @@ class Context:
     def set_tuning(self, reduce_splits: int = 0, general: bool = False):
         self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general)))
 
+    def set_queue_items(self, items: int):
+        self._check(self.lib.ampli_set_queue_items(self.h, items))
+
     def flags(self, clear: bool = True) -> int:
         """AMPLI_FLAG_* raised by kernels since the last clear (synchronises)."""
         out = C.c_int32()
@@ -197,26 +203,33 @@ class Context:
         assert trecs.numel() == T * R * 8
         d = self.device
         if call_mask is None:
-            call_mask = torch.empty((T, R), dtype=torch.uint8, device=d)
+            call_mask = torch.empty(((T * R + 3) // 4 * 4,), dtype=torch.uint8, device=d)[: T * R].view(T, R)
         q = torch.empty((T, R, 4, 2), dtype=torch.float64, device=d) if dense_q else None
         af = torch.empty((T, R, 4, 3), dtype=torch.float32, device=d) if dense_af else None
         if capacity > 0 and calls_buf is None:
             calls_buf = torch.empty((capacity * C.sizeof(Call),), dtype=torch.uint8, device=d)
+        if capacity > 0:
+            capacity -= capacity % CALL_SHARDS
         if (capacity > 0 or n_calls is not None) and n_calls is None:
-            n_calls = torch.zeros((1,), dtype=torch.int64, device=d)
+            n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=d)
         self._check(self.lib.ampli_poisson_call(self.h, _ptr(trecs), P, E, _ptr(ext_pos), T, _ptr(thr), _ptr(ref_code), cov,
                                                 mode, _ptr(call_mask), _ptr(calls_buf), capacity, _ptr(n_calls), _ptr(q), _ptr(af)))
-        return dict(call_mask=call_mask, q=q, af=af, calls_buf=calls_buf, n_calls=n_calls)
+        return dict(call_mask=call_mask, q=q, af=af, calls_buf=calls_buf, n_calls=n_calls, capacity=capacity)
+
+    @staticmethod
+    def n_calls_total(res) -> int:
+        return int(res["n_calls"][::CALL_COUNTER_STRIDE].sum().item())
 
     def read_calls(self, res) -> list[dict]:
         """Copy the compact call list to the host, sorted into the reference's emission order."""
         import numpy as np
 
-        n = int(res["n_calls"].item())
-        cap = res["calls_buf"].numel() // C.sizeof(Call)
-        if n > cap:
-            raise AmpliError(f"call list capacity exceeded: {n} > {cap}")
-        raw = res["calls_buf"][: n * C.sizeof(Call)].cpu().numpy().tobytes()
+        counts = res["n_calls"][::CALL_COUNTER_STRIDE].cpu().numpy()
+        per = res["capacity"] // CALL_SHARDS
+        if (counts > per).any():
+            raise AmpliError(f"call list segment overflowed: {int(counts.max())} > {per}; rerun with a larger capacity")
+        sz = C.sizeof(Call)
+        raw = b"".join(res["calls_buf"][k * per * sz: (k * per + int(counts[k])) * sz].cpu().numpy().tobytes() for k in range(CALL_SHARDS))
         dt = np.dtype([("sample", "<i4"), ("record", "<i4"), ("alt", "<i4"), ("pad", "<i4"), ("q_fw", "<f8"),
                        ("q_bw", "<f8"), ("af", "<f4"), ("af_fw", "<f4"), ("af_bw", "<f4"), ("pad2", "<f4")])
         a = np.frombuffer(raw, dtype=dt)

@@ -10,6 +10,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,6 +32,10 @@ struct ampli_ctx {
     int reduce_splits = 0; // 0 = auto
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
+    void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
+    size_t queue_items = 0;
+    size_t queue_min_items = 0; // ampli_set_queue_items
+    unsigned long long *queue_n = nullptr;
     int n_cu = 256;
 };
 
@@ -106,6 +111,8 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+    if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->queue_n) (void)hipFree(ctx->queue_n);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -185,6 +192,13 @@ extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, in
     if (!ctx || reduce_sample_splits < 0) return AMPLI_E_INVALID;
     ctx->reduce_splits = reduce_sample_splits;
     ctx->reduce_general = reduce_general ? 1 : 0;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_set_queue_items(ampli_ctx *ctx, int64_t items)
+{
+    if (!ctx || items < 0) return AMPLI_E_INVALID;
+    ctx->queue_min_items = (size_t)items;
     return AMPLI_OK;
 }
 
@@ -488,7 +502,13 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
 // split for acc_merge_kernel.
 // ---------------------------------------------------------------------------
 constexpr int RED_WAVES = 4;
-constexpr int RED_UNROLL = 2;
+#ifndef AMPLI_RED_UNROLL
+#define AMPLI_RED_UNROLL 1
+#endif
+#ifndef AMPLI_RED_PINGPONG
+#define AMPLI_RED_PINGPONG 0
+#endif
+constexpr int RED_UNROLL = AMPLI_RED_UNROLL;
 
 __device__ __forceinline__ void fast_to_lane(const FastAcc &f, LaneAcc &a)
 {
@@ -542,34 +562,24 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     if (E > 0) { e0 = dup_off[p]; e1 = dup_off[p + 1]; }
     const bool any_dup = E > 0 && __any(e1 > e0);
 
-    int4 b0[RED_UNROLL], b1[RED_UNROLL];
-    // prologue: first batch
+    // Two register batches of RED_UNROLL sample rows, ping-pong: one is being consumed while the loads of the
+    // other are in flight (no copies between them).
+    int4 a0[RED_UNROLL], a1[RED_UNROLL], b0[RED_UNROLL], b1[RED_UNROLL];
+    auto load_batch = [&](int4 (&x0)[RED_UNROLL], int4 (&x1)[RED_UNROLL], const int s) {
 #pragma unroll
-    for (int u = 0; u < RED_UNROLL; ++u) {
-        const int s = min(s0 + u, S - 1);
-        const int4 *q = recs + ((size_t)s * R + p) * 2;
-        b0[u] = q[0];
-        b1[u] = q[1];
-    }
-    for (int s = s0; s < s1; s += RED_UNROLL) {
-        int4 c0[RED_UNROLL], c1[RED_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) { c0[u] = b0[u]; c1[u] = b1[u]; }
-        // prefetch the next batch while this one is processed
-        if (s + RED_UNROLL < s1) {
-#pragma unroll
-            for (int u = 0; u < RED_UNROLL; ++u) {
-                const int sn = min(s + RED_UNROLL + u, S - 1);
-                const int4 *q = recs + ((size_t)sn * R + p) * 2;
-                b0[u] = q[0];
-                b1[u] = q[1];
-            }
+        for (int u = 0; u < RED_UNROLL; ++u) {
+            const int sn = min(s + u, S - 1); // clamped rows are loaded but never visited
+            const int4 *q = recs + ((size_t)sn * R + p) * 2;
+            x0[u] = q[0];
+            x1[u] = q[1];
         }
+    };
+    auto visit_batch = [&](const int4 (&x0)[RED_UNROLL], const int4 (&x1)[RED_UNROLL], const int s) {
 #pragma unroll
         for (int u = 0; u < RED_UNROLL; ++u) {
             if (s + u < s1) {
-                if (FAST) visit_fast(f, c0[u], c1[u], first_sample + s + u, C, cov);
-                else visit_record(a, c0[u], c1[u], first_sample + s + u, C, cov);
+                if (FAST) visit_fast(f, x0[u], x1[u], first_sample + s + u, C, cov);
+                else visit_record(a, x0[u], x1[u], first_sample + s + u, C, cov);
                 if (any_dup) { // extras of this position in the same sample, in file order
                     for (unsigned e = e0; e < e1; ++e) {
                         const int4 *q = recs + ((size_t)(s + u) * R + (size_t)P + e) * 2;
@@ -579,7 +589,23 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
                 }
             }
         }
+    };
+    load_batch(a0, a1, s0);
+#if AMPLI_RED_PINGPONG
+    for (int s = s0; s < s1; s += 2 * RED_UNROLL) {
+        if (s + RED_UNROLL < s1) load_batch(b0, b1, s + RED_UNROLL);
+        visit_batch(a0, a1, s);
+        if (s + 2 * RED_UNROLL < s1) load_batch(a0, a1, s + 2 * RED_UNROLL);
+        if (s + RED_UNROLL < s1) visit_batch(b0, b1, s + RED_UNROLL);
     }
+#else
+    for (int s = s0; s < s1; s += RED_UNROLL) {
+#pragma unroll
+        for (int u = 0; u < RED_UNROLL; ++u) { b0[u] = a0[u]; b1[u] = a1[u]; }
+        if (s + RED_UNROLL < s1) load_batch(a0, a1, s + RED_UNROLL); // prefetch while this batch is consumed
+        visit_batch(b0, b1, s);
+    }
+#endif
     if (FAST) {
         if (f.bad || f.nrec > FAST_MAX_RECORDS) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
         fast_to_lane(f, a);
@@ -746,6 +772,18 @@ __global__ __launch_bounds__(256) void error_finalize_kernel(AccPtrs t, const lo
 // workgroup so the position's 8 thresholds + reference code are loaded once
 // and reused from registers.
 // ---------------------------------------------------------------------------
+// Compact call list, sharded: a returning atomic on ONE word serialises at ~11 ns per add (about 90 per us chip-wide,
+// MI355X_MICROARCH.md "dequeue"), which at a few thousand calls per launch would bound the whole kernel.  The list is
+// therefore AMPLI_CALL_SHARDS independent segments, each with its own counter on its own 128-byte line; a workgroup
+// appends to the shard blockIdx.x % AMPLI_CALL_SHARDS.  Segment k holds entries [k*cap_per_shard, ...).
+__device__ __forceinline__ long long call_slot(unsigned long long *__restrict__ n_calls, const long long capacity)
+{
+    const unsigned shard = blockIdx.x % AMPLI_CALL_SHARDS;
+    const long long per = capacity / AMPLI_CALL_SHARDS;
+    const unsigned long long i = atomicAdd(&n_calls[shard * AMPLI_CALL_COUNTER_STRIDE], 1ull);
+    return ((long long)i < per) ? (long long)shard * per + (long long)i : -1;
+}
+
 constexpr int PC_SAMPLES = 4;
 
 template <int MODE>
@@ -813,8 +851,8 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
                 if (covok && q_fw >= 5 && q_bw >= 5) { // VC:898
                     mask |= 1u << nt;
                     if (n_calls) {
-                        const unsigned long long idx = atomicAdd(n_calls, 1ull);
-                        if (calls && (long long)idx < capacity) {
+                        const long long idx = call_slot(n_calls, capacity);
+                        if (calls && idx >= 0) {
                             ampli_call c;
                             c.sample = t; c.record = (int)r; c.alt = nt; c.pad = 0;
                             c.q_fw = q_fw; c.q_bw = q_bw;
@@ -833,60 +871,106 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// poisson_call, prefilter mode: streaming pass + LDS work queue.
-// Most (record, alt) pairs are settled by integer/one-multiply tests (coverage,
-// k == 0, k <= m: ampli_prefilter_nocall).  The survivors -- real variants and
-// noisy cells, a few per cent -- are not evaluated in place (one slow lane would
-// stall its 63 neighbours for ~100 fp64 iterations); they are appended to a
-// queue in LDS and the whole workgroup drains it densely: two adjacent lanes
-// per item, one per strand.  Workgroup = 256 positions x PCQ_SAMPLES tumours.
+// poisson_call, prefilter mode = two kernels.
+//
+// poisson_stream_kernel: one lane per position, PCS_SAMPLES tumour rows per workgroup; thresholds, reference
+//   code and the derived per-position constants stay in registers across the rows.  Most (record, alt) pairs are
+//   settled by a conservative fp32 form of the exact bound "k <= m = RD*err => Q < 5" (ampli_prefilter_nocall):
+//       skip  <=>  float(k) <= (float(RD) * 0.999999f) * err_eff
+//   which implies k < m (both operands are exact floats below 2^24 and the product is rounded below RD*err), with
+//   err_eff = +inf for err == -1 (Q = -888) and 0.0010008f for err == 0.  Anything not provably skippable -- real
+//   variants, noisy cells, the rounding fringe: ~0.2 % of the records -- is appended to a queue in HBM.
+// poisson_drain_kernel: evaluates the queue DENSELY, two adjacent lanes per item (one per strand) with the full
+//   kf scorer, ORs the call bits into the mask and appends the compact call records.
+//
+// Evaluating survivors in place would stall 63 lanes behind one ~100-iteration fp64 loop; draining per wave from
+// LDS (an earlier version) still paid one such loop per wave for a couple of items.  The dense second kernel pays
+// it once per 32 items.
 // ---------------------------------------------------------------------------
-constexpr int PCQ_SAMPLES = 8;
-constexpr int PCQ_CAP = 1024;          // queue capacity in items
-constexpr int PCQ_DRAIN_AT = PCQ_CAP - 3 * 256; // one more sample row (<= 768 items) always fits
+constexpr int PCS_SAMPLES = 16;
 
-struct PcqShared {
-    int item[8][PCQ_CAP]; // SoA: {slot, alt, k_fw, d_fw, e_fw(bits), k_bw, d_bw, e_bw(bits)}
-    unsigned mask[PCQ_SAMPLES][64]; // 256 mask bytes per sample row, as words for LDS atomics
-    int qn;
+struct PcItem { // 32 bytes
+    int sample, record, alt_pad;
+    int k_fw, d_fw, k_bw, d_bw;
+    int pad;
 };
 
-__device__ __forceinline__ void pcq_drain(PcqShared &sh, const int n_items, const int t0, const long long r0,
-                                          const long long R, const int4 *__restrict__ recs,
-                                          ampli_call *__restrict__ calls, const long long capacity,
-                                          unsigned long long *__restrict__ n_calls)
+__global__ __launch_bounds__(256) void poisson_stream_kernel(
+    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
+    const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
+    PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
+    int *__restrict__ flags)
 {
-    const int tid = threadIdx.x;
-    for (int base = 0; base < 2 * n_items; base += 256) {
-        const int e = base + tid;
-        if (e < 2 * n_items) {
-            const int it = e >> 1, strand = e & 1;
-            const int k = sh.item[2 + 3 * strand][it];
-            const int d = sh.item[3 + 3 * strand][it];
-            const float err = __int_as_float(sh.item[4 + 3 * strand][it]);
-            const double q = ampli_poisson_score(k, d, err);
-            const double q_other = __shfl_xor(q, 1);
-            if (strand == 0 && q >= 5 && q_other >= 5) { // VC:898 (coverage was checked when the item was queued)
-                const int slot = sh.item[0][it], alt = sh.item[1][it];
-                const int dt = slot >> 8, lr = slot & 255;
-                atomicOr(&sh.mask[dt][lr >> 2], (1u << alt) << ((lr & 3) * 8));
-                if (n_calls) {
-                    const unsigned long long idx = atomicAdd(n_calls, 1ull);
-                    if (calls && (long long)idx < capacity) {
-                        const int t = t0 + dt;
-                        const long long r = r0 + lr;
-                        const size_t o = (size_t)t * R + r;
-                        const int4 a0 = recs[o * 2], a1 = recs[o * 2 + 1]; // L2-hot: streamed moments ago
-                        const int fw[4] = {a0.x, a0.y, a0.z, a0.w}, bw[4] = {a1.x, a1.y, a1.z, a1.w};
-                        const int FW = fw[0] + fw[1] + fw[2] + fw[3], BW = bw[0] + bw[1] + bw[2] + bw[3];
-                        ampli_call c;
-                        c.sample = t; c.record = (int)r; c.alt = alt; c.pad = 0;
-                        c.q_fw = q; c.q_bw = q_other;
-                        c.af = (float)(fw[alt] + bw[alt]) / (float)(FW + BW);   // VC:814-817
-                        c.af_fw = FW == 0 ? 0.0f : (float)fw[alt] / (float)FW;  // VC:785-790
-                        c.af_bw = BW == 0 ? 0.0f : (float)bw[alt] / (float)BW;  // VC:805-810
-                        c.pad2 = 0.0f;
-                        calls[idx] = c;
+    const int lane = threadIdx.x & 63;
+    const long long R = P + E;
+    const long long r_raw = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = r_raw < R;
+    const long long r = valid ? r_raw : R - 1;
+    const long long p = r < P ? r : (long long)ext_pos[r - P];
+    const int t0 = blockIdx.y * PCS_SAMPLES;
+    const int nt_rows = min(PCS_SAMPLES, T - t0);
+    const int ref = valid ? (int)ref_code[p] : 255;
+
+    float te[2][4]; // effective error per strand / nucleotide
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            te[st][nt] = ampli_effective_err(thr[(st * 4 + nt) * P + p]); // VC:887-890
+        }
+    }
+    const unsigned shard = blockIdx.x % AMPLI_CALL_SHARDS;
+
+    const size_t row_stride = (size_t)R * 2;
+    const int4 *row = recs + ((size_t)t0 * R + r) * 2;
+    int4 n0 = row[0], n1 = row[1];
+    for (int dt = 0; dt < nt_rows; ++dt) {
+        const int4 r0v = n0, r1v = n1;
+        if (dt + 1 < nt_rows) { // prefetch the next sample row
+            row += row_stride;
+            n0 = row[0];
+            n1 = row[1];
+        }
+        const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
+        const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
+        const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
+        const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
+        const int RD = FW + BW;
+        const int d_fw = RD - BW, d_bw = BW;          // VC:895-896
+        const bool live = valid && r0v.x != AMPLI_ABSENT && ref <= 3 && FW >= cov && BW >= cov; // VC:898, VC:3290
+        // conservative fp32 bound (ampli_prefilter_skip_f32, hoisted); depths or counts >= 2^24 are not exact
+        // floats: never skip those
+        const bool exact = (unsigned)RD < (unsigned)AMPLI_COUNT_LIMIT && FW >= 0 && BW >= 0;
+        const float c_fw = (float)d_fw * 0.999999f, c_bw = (float)d_bw * 0.999999f;
+        unsigned pushmask = 0;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const bool skip_fw = exact && (unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)fw[nt] <= c_fw * te[0][nt];
+            const bool skip_bw = exact && (unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)bw[nt] <= c_bw * te[1][nt];
+            if (live && nt != ref && !skip_fw && !skip_bw) pushmask |= 1u << nt;
+        }
+        if (__any(pushmask != 0)) { // rare
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bool push = (pushmask >> nt) & 1;
+                const unsigned long long bal = __ballot(push);
+                if (bal) {
+                    const int n = __popcll(bal);
+                    unsigned long long base = 0;
+                    if (lane == (int)__ffsll((long long)bal) - 1)
+                        base = atomicAdd(&queue_n[shard * AMPLI_CALL_COUNTER_STRIDE], (unsigned long long)n);
+                    base = __shfl(base, (int)__ffsll((long long)bal) - 1);
+                    if (push) {
+                        const long long i = (long long)base +
+                                            __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                        if (i < queue_per_shard) {
+                            PcItem it;
+                            it.sample = t0 + dt; it.record = (int)r; it.alt_pad = nt;
+                            it.k_fw = fw[nt]; it.d_fw = d_fw; it.k_bw = bw[nt]; it.d_bw = d_bw; it.pad = 0;
+                            queue[(size_t)shard * queue_per_shard + i] = it;
+                        } else {
+                            atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
+                        }
                     }
                 }
             }
@@ -894,74 +978,72 @@ __device__ __forceinline__ void pcq_drain(PcqShared &sh, const int n_items, cons
     }
 }
 
-__global__ __launch_bounds__(256) void poisson_call_queue_kernel(
+__global__ __launch_bounds__(256) void poisson_drain_kernel(
+    const PcItem *__restrict__ queue, const long long queue_per_shard, const unsigned long long *__restrict__ queue_n,
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
-    const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
-    unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
-    unsigned long long *__restrict__ n_calls)
+    const float *__restrict__ thr, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls,
+    const long long capacity, unsigned long long *__restrict__ n_calls)
 {
-    __shared__ PcqShared sh;
-    const int tid = threadIdx.x;
     const long long R = P + E;
-    const long long r0 = (long long)blockIdx.x * 256;
-    const long long r_raw = r0 + tid;
-    const bool valid = r_raw < R;
-    const long long r = valid ? r_raw : R - 1;
-    const long long p = r < P ? r : (long long)ext_pos[r - P];
-    const int t0 = blockIdx.y * PCQ_SAMPLES;
-    const int nt_rows = min(PCQ_SAMPLES, T - t0);
-
-    float th[2][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        th[0][nt] = thr[(0 * 4 + nt) * P + p]; // VC:887-890
-        th[1][nt] = thr[(1 * 4 + nt) * P + p];
-    }
-    const int ref = valid ? (int)ref_code[p] : 255;
-    for (int i = tid; i < PCQ_SAMPLES * 64; i += 256) (&sh.mask[0][0])[i] = 0u;
-    if (tid == 0) sh.qn = 0;
-    __syncthreads();
-
-    int4 n0 = recs[((size_t)t0 * R + r) * 2], n1 = recs[((size_t)t0 * R + r) * 2 + 1];
-    for (int dt = 0; dt < nt_rows; ++dt) {
-        const int4 r0v = n0, r1v = n1;
-        if (dt + 1 < nt_rows) { // prefetch the next sample row
-            const size_t o = ((size_t)(t0 + dt + 1) * R + r) * 2;
-            n0 = recs[o];
-            n1 = recs[o + 1];
+    const long long nthreads = (long long)gridDim.x * blockDim.x;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // the shards form one flat index space: cum[k] = items in shards < k (clamped to the segment size)
+    __shared__ long long cum[AMPLI_CALL_SHARDS + 1];
+    if (threadIdx.x == 0) {
+        long long c = 0;
+        for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
+            cum[k] = c;
+            long long n = (long long)queue_n[k * AMPLI_CALL_COUNTER_STRIDE];
+            c += n > queue_per_shard ? queue_per_shard : n;
         }
-        const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
-        const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
-        const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
-        const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
-        const int RD = FW + BW;
-        const bool live = valid && r0v.x != AMPLI_ABSENT && ref <= 3 && FW >= cov && BW >= cov; // VC:898, VC:3290
-        if (live) {
+        cum[AMPLI_CALL_SHARDS] = c;
+    }
+    __syncthreads();
+    const long long n_evals = 2 * cum[AMPLI_CALL_SHARDS];
+    {
+        // two adjacent lanes per item; the loop runs in whole waves so that a pair is always together
+        for (long long base = (tid & ~63ll); base < n_evals; base += nthreads) {
+            const long long e = base + (tid & 63);
+            const bool on = e < n_evals;
+            double qv = 0.0;
+            PcItem it;
+            int strand = (int)(e & 1);
+            if (on) {
+                const long long g = e >> 1;
+                int shard = 0;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                if (nt == ref) continue;
-                const int k_fw = fw[nt], d_fw = RD - BW, k_bw = bw[nt], d_bw = BW; // VC:895-896
-                if (ampli_prefilter_nocall(k_fw, d_fw, th[0][nt]) || ampli_prefilter_nocall(k_bw, d_bw, th[1][nt])) continue;
-                const int slot = atomicAdd(&sh.qn, 1);
-                sh.item[0][slot] = (dt << 8) | tid;
-                sh.item[1][slot] = nt;
-                sh.item[2][slot] = k_fw; sh.item[3][slot] = d_fw; sh.item[4][slot] = __float_as_int(th[0][nt]);
-                sh.item[5][slot] = k_bw; sh.item[6][slot] = d_bw; sh.item[7][slot] = __float_as_int(th[1][nt]);
+                for (int step = AMPLI_CALL_SHARDS / 2; step > 0; step >>= 1)
+                    if (cum[shard + step] <= g) shard += step;
+                it = queue[(size_t)shard * queue_per_shard + (g - cum[shard])];
+                const long long p = it.record < P ? it.record : (long long)ext_pos[it.record - P];
+                const float err = thr[(strand * 4 + it.alt_pad) * P + p];
+                qv = ampli_poisson_score(strand ? it.k_bw : it.k_fw, strand ? it.d_bw : it.d_fw, err); // VC:895-896
+            }
+            const double q_other = __shfl_xor(qv, 1);
+            if (on && strand == 0 && qv >= 5 && q_other >= 5) { // VC:898 (coverage was checked before queueing)
+                const size_t o = (size_t)it.sample * R + it.record;
+                atomicOr(&mask_words[o >> 2], (1u << it.alt_pad) << ((o & 3) * 8));
+                if (n_calls) {
+                    const unsigned cs = (unsigned)(blockIdx.x % AMPLI_CALL_SHARDS);
+                    const long long per = capacity / AMPLI_CALL_SHARDS;
+                    const unsigned long long i = atomicAdd(&n_calls[cs * AMPLI_CALL_COUNTER_STRIDE], 1ull);
+                    if (calls && (long long)i < per) {
+                        const int4 a0 = recs[o * 2], a1 = recs[o * 2 + 1];
+                        const int fw[4] = {a0.x, a0.y, a0.z, a0.w}, bw[4] = {a1.x, a1.y, a1.z, a1.w};
+                        const int FW = fw[0] + fw[1] + fw[2] + fw[3], BW = bw[0] + bw[1] + bw[2] + bw[3];
+                        const int alt = it.alt_pad;
+                        ampli_call c;
+                        c.sample = it.sample; c.record = it.record; c.alt = alt; c.pad = 0;
+                        c.q_fw = qv; c.q_bw = q_other;
+                        c.af = (float)(fw[alt] + bw[alt]) / (float)(FW + BW);   // VC:814-817
+                        c.af_fw = FW == 0 ? 0.0f : (float)fw[alt] / (float)FW;  // VC:785-790
+                        c.af_bw = BW == 0 ? 0.0f : (float)bw[alt] / (float)BW;  // VC:805-810
+                        c.pad2 = 0.0f;
+                        calls[(size_t)cs * per + i] = c;
+                    }
+                }
             }
         }
-        __syncthreads();
-        const int qn = sh.qn;
-        if (qn > PCQ_DRAIN_AT || dt + 1 == nt_rows) { // block-uniform
-            pcq_drain(sh, qn, t0, r0, R, recs, calls, capacity, n_calls);
-            __syncthreads();
-            if (tid == 0) sh.qn = 0;
-            __syncthreads();
-        }
-    }
-    // mask rows out, one byte per record
-    if (valid) {
-        for (int dt = 0; dt < nt_rows; ++dt)
-            call_mask[(size_t)(t0 + dt) * R + r_raw] = (unsigned char)((sh.mask[dt][tid >> 2] >> ((tid & 3) * 8)) & 0xFF);
     }
 }
 
@@ -1168,7 +1250,8 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
     if (E > 0 && !d_ext_pos) return fail(ctx, AMPLI_E_INVALID, "poisson_call: E > 0 needs ext_pos");
     if (mode != AMPLI_POISSON_FULL && mode != AMPLI_POISSON_PREFILTER) return fail(ctx, AMPLI_E_INVALID, "poisson_call: bad mode");
     if (d_q && mode != AMPLI_POISSON_FULL) return fail(ctx, AMPLI_E_INVALID, "poisson_call: dense q needs AMPLI_POISSON_FULL");
-    if (d_calls && (!d_n_calls || capacity <= 0)) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call list needs n_calls and capacity");
+    if (d_calls && (!d_n_calls || capacity < AMPLI_CALL_SHARDS)) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call list needs n_calls and capacity >= AMPLI_CALL_SHARDS");
+    if (d_n_calls && !d_calls) capacity = 0;
     if (((uintptr_t)d_trecs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long R = P + E;
@@ -1182,10 +1265,32 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
                            (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
                            (long long)capacity, d_n_calls, d_q, d_af);
     else {
-        dim3 qgrid((unsigned)((R + 255) / 256), (unsigned)((T + PCQ_SAMPLES - 1) / PCQ_SAMPLES));
-        hipLaunchKernelGGL(poisson_call_queue_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,
-                           (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
-                           (long long)capacity, d_n_calls);
+        // queue workspace: T*R/4 items (the synthetic and Toy_data panels queue ~0.2 % of the records), grown on demand
+        size_t want = (size_t)std::max<long long>(1 << 16, (long long)T * R / 4);
+        if (ctx->queue_min_items > want) want = ctx->queue_min_items;
+        want = (want + AMPLI_CALL_SHARDS - 1) / AMPLI_CALL_SHARDS * AMPLI_CALL_SHARDS;
+        if (ctx->queue_items < want) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->queue) (void)hipFree(ctx->queue);
+            ctx->queue = nullptr; ctx->queue_items = 0;
+            if (hipMalloc(&ctx->queue, want * sizeof(PcItem)) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "queue hipMalloc failed");
+            ctx->queue_items = want;
+        }
+        if (!ctx->queue_n && hipMalloc((void **)&ctx->queue_n, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS) != hipSuccess)
+            return fail(ctx, AMPLI_E_NOMEM, "queue counter hipMalloc failed");
+        if (((uintptr_t)d_call_mask & 3) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call_mask must be 4-byte aligned");
+        const long long per = (long long)(ctx->queue_items / AMPLI_CALL_SHARDS);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->queue_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_call_mask, 0, (size_t)T * R, ctx->stream));
+        dim3 qgrid((unsigned)((R + 255) / 256), (unsigned)((T + PCS_SAMPLES - 1) / PCS_SAMPLES));
+        hipLaunchKernelGGL(poisson_stream_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P, (long long)E,
+                           d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, ctx->queue_n, ctx->d_flags);
+        int rc = check_launch(ctx, "poisson_stream_kernel");
+        if (rc) return rc;
+        hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, ctx->stream, (const PcItem *)ctx->queue,
+                           per, ctx->queue_n, (const int4 *)d_trecs, (long long)P, (long long)E, d_ext_pos, d_thr,
+                           (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls);
+        return check_launch(ctx, "poisson_drain_kernel");
     }
     return check_launch(ctx, "poisson_call_kernel");
 }

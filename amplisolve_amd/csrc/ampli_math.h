@@ -180,4 +180,22 @@ AMPLI_FN int ampli_prefilter_nocall(int32_t k, int32_t rd, float err)
     return (double)k <= m;
 }
 
+// Conservative fp32 form of the bound above, used by the streaming kernel: with err_eff = ampli_effective_err(err)
+// and c = float(rd) * 0.999999f,   float(k) <= c * err_eff   implies   k <= rd * err   (k, rd < 2^24 are exact
+// floats; two roundings of at most 2^-24 each cannot undo the factor 1 - 1e-6), so every record it skips would be
+// skipped by ampli_prefilter_nocall too.  What it does not skip is scored exactly; nothing is decided in fp32.
+AMPLI_FN float ampli_effective_err(float err)
+{
+    if (err == 0.0f) return 0.0010008f; // VC:3852-3856
+    if (err == -1.0f) return INFINITY;  // VC:3844-3849: Q = -888
+    return err;
+}
+
+AMPLI_FN int ampli_prefilter_skip_f32(int32_t k, int32_t rd, float err_eff)
+{
+    if ((uint32_t)rd >= (uint32_t)AMPLI_COUNT_LIMIT || (uint32_t)k >= (uint32_t)AMPLI_COUNT_LIMIT) return 0;
+    const float c = (float)rd * 0.999999f;
+    return (float)k <= c * err_eff;
+}
+
 #endif

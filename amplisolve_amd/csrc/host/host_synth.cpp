@@ -28,3 +28,4 @@ extern "C" void ampli_host_text_roundtrip_batch(const float *in, int64_t n, floa
 
 extern "C" int32_t ampli_host_af_limit(int32_t d) { return ampli_af_limit(d); }
 extern "C" int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err) { return ampli_prefilter_nocall(k, rd, err); }
+extern "C" int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err) { return ampli_prefilter_skip_f32(k, rd, ampli_effective_err(err)); }

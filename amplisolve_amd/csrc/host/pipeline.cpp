@@ -277,23 +277,29 @@ int run_variant_calling(const VcArgs &a)
             float *d_thr = dev.upload(thr.data(), thr.size());
             uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
             uint8_t *d_mask = dev.alloc<uint8_t>((size_t)T * R);
-            unsigned long long *d_n = dev.alloc<unsigned long long>(1);
+            unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
             int64_t cap = std::max<int64_t>(1 << 16, (int64_t)T * R / 16);
-            for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int attempt = 0; attempt < 3; ++attempt) {
+                cap -= cap % AMPLI_CALL_SHARDS;
+                const int64_t per = cap / AMPLI_CALL_SHARDS;
                 ampli_call *d_calls = dev.alloc<ampli_call>((size_t)cap);
-                dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long)), "memset");
+                dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
                 dev.check(dev.api->poisson_call(dev.ctx, d_recs, P, co.E, d_ext, T, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask,
                                                 d_calls, cap, d_n, nullptr, nullptr), "ampli_poisson_call");
-                unsigned long long n = 0;
-                dev.download(&n, d_n, 1);
+                std::vector<unsigned long long> n(AMPLI_CALL_COUNTER_WORDS);
+                dev.download(n.data(), d_n, n.size());
                 dev.sync();
-                if ((int64_t)n > cap) { cap = (int64_t)n; continue; } // list overflowed: rerun with the exact size
-                std::vector<ampli_call> calls((size_t)n);
-                dev.download(calls.data(), d_calls, (size_t)n);
-                dev.sync();
-                rows.reserve(calls.size());
-                for (auto &c : calls)
-                    rows.push_back(CallRow{c.sample, co.line_no[(size_t)c.sample * R + c.record], c.alt, c.record, c.q_fw, c.q_bw, c.af, c.af_fw, c.af_bw});
+                unsigned long long worst = 0;
+                for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) worst = std::max(worst, n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE]);
+                if ((int64_t)worst > per) { cap = (int64_t)worst * AMPLI_CALL_SHARDS; continue; } // a segment overflowed: rerun, sized for it
+                for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
+                    const size_t cnt = (size_t)n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
+                    std::vector<ampli_call> calls(cnt);
+                    if (cnt) dev.download(calls.data(), d_calls + (size_t)k * per, cnt);
+                    dev.sync();
+                    for (auto &c : calls)
+                        rows.push_back(CallRow{c.sample, co.line_no[(size_t)c.sample * R + c.record], c.alt, c.record, c.q_fw, c.q_bw, c.af, c.af_fw, c.af_bw});
+                }
                 break;
             }
         }

@@ -181,7 +181,9 @@ def main():
     import ctypes
 
     calls_buf = torch.empty((cap * ctypes.sizeof(Call),), dtype=torch.uint8, device=ctx.device)
-    n_calls = torch.zeros((1,), dtype=torch.int64, device=ctx.device)
+    from amplisolve_amd.api import CALL_COUNTER_STRIDE, CALL_COUNTER_WORDS
+
+    n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=ctx.device)
     gather_buf = None
     if world > 1:
         _, _, gm_bytes = ctx.regions(P)
@@ -228,7 +230,7 @@ def main():
 
     t_red = sum(ctx.elapsed_ms(e[0], e[1]) for e in ev) / args.steps
     t_call = sum(ctx.elapsed_ms(e[2], e[3]) for e in ev) / args.steps
-    n_found = int(n_calls.item())
+    n_found = int(n_calls[::CALL_COUNTER_STRIDE].sum().item())
     # validation mode, outside the timed region: all six scores of every record, as the reference evaluates them
     e0, e1 = ctx.event(), ctx.event()
     n_calls.zero_()

@@ -179,6 +179,10 @@ typedef struct ampli_call {
     float af, af_fw, af_bw, pad2; /* VC:772-817: the reported VAFs */
 } ampli_call;
 
+#define AMPLI_CALL_SHARDS 32
+#define AMPLI_CALL_COUNTER_STRIDE 16 /* uint64 words between shard counters: one 128-byte line each */
+#define AMPLI_CALL_COUNTER_WORDS (AMPLI_CALL_SHARDS * AMPLI_CALL_COUNTER_STRIDE)
+
 #define AMPLI_POISSON_FULL 0      /* evaluate all 6 scores of every record, as the reference does */
 #define AMPLI_POISSON_PREFILTER 1 /* skip scores an exact bound proves < 5 (identical outputs) */
 
@@ -188,10 +192,14 @@ typedef struct ampli_call {
  * (VC:3721-3884) for T tumour samples.
  *   d_thr [2][4][P] as produced by error_finalize or parsed from the table (std::stof, VC:889-890)
  *   d_ref_code [P]  0..3 = A,C,G,T; 255 = reference base not in ACGT -> record skipped (VC:3290)
- *   d_call_mask [T][R] uint8: bit a set = alt nucleotide a called at that record
- *   d_calls / capacity / d_n_calls: optional compact list of emitted calls (unordered; sort by
- *     (sample, record, alt) to get the reference's emission order); *d_n_calls counts all calls,
- *     entries beyond capacity are dropped.  d_n_calls must be zeroed by the caller (ampli_memset_d).
+ *   d_call_mask [T][R] uint8: bit a set = alt nucleotide a called at that record (4-byte aligned buffer,
+ *     rounded up to a multiple of 4 bytes)
+ *   d_calls / capacity / d_n_calls: optional compact list of emitted calls, kept as AMPLI_CALL_SHARDS independent
+ *     segments so that appends do not serialise on one counter: segment k = entries [k*(capacity/SHARDS), ...),
+ *     its fill count is d_n_calls[k*AMPLI_CALL_COUNTER_STRIDE] (a count above capacity/SHARDS means that segment
+ *     overflowed: rerun with a larger capacity).  d_n_calls points to AMPLI_CALL_COUNTER_WORDS uint64 words that the
+ *     caller zeroes (ampli_memset_d).  Entries are unordered: sort by (sample, record, alt) for the reference's
+ *     emission order.  d_n_calls without d_calls just counts.
  *   d_q [T][R][4][2] double, optional dense scores (Q_fw,Q_bw per nucleotide; -1 = not evaluated;
  *     requires mode FULL); d_af [T][R][4][3] float optional dense {AF, AF_fw, AF_bw}.
  */
@@ -220,7 +228,12 @@ int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t see
  * kernel that follows the reference operation by operation for any depth (slower). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general);
 
+/* Minimum capacity (items of 32 B) of the prefilter queue of ampli_poisson_call; default T*R/4, at least 65536. */
+int ampli_set_queue_items(ampli_ctx *ctx, int64_t items);
+
 /* Flags raised by kernels of this context since the last clear (synchronises the stream). */
+#define AMPLI_FLAG_QUEUE_OVERFLOW 4 /* poisson_call (prefilter) ran out of queue space: masks/calls incomplete, raise
+                                       ampli_set_queue_items (or use AMPLI_POISSON_FULL) and rerun */
 #define AMPLI_FLAG_RERUN_GENERAL 2 /* error_reduce met a depth >= 2^22: its table is invalid, rerun with reduce_general = 1 */
 int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear);
 

@@ -29,6 +29,7 @@ int ampli_host_synth_ref(uint8_t *ref_code /*[P]*/, int64_t P, uint64_t seed);
 void ampli_host_text_roundtrip_batch(const float *in, int64_t n, float *out);
 int32_t ampli_host_af_limit(int32_t d);
 int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err);
+int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err); /* the streaming kernel's fp32 form */
 
 /* ---- panel + cohort: BED (or error table) + a directory of .PILEUP.ASEQ packed into the record SoA ---- */
 typedef struct ampli_host_cohort ampli_host_cohort;

@@ -78,3 +78,28 @@ def test_prefilter_bound_is_exact_decision():
     # and the complement is not skipped
     assert H.ampli_host_prefilter_nocall(3, 1000, 0.002) == 0 and H.ampli_host_prefilter_nocall(2, 1000, 0.002) == 1
     assert H.ampli_host_prefilter_nocall(5, 1000, -1.0) == 1 and H.ampli_host_prefilter_nocall(0, 1000, 0.002) == 1
+
+
+def test_fp32_prefilter_is_conservative():
+    """The streaming kernel's fp32 test may only skip what the exact bound skips (k <= RD*err in double)."""
+    H = host_lib()
+    rng = np.random.default_rng(8)
+    errs = np.array([0.0001, 0.0005, 0.001, 0.002, 0.002189, 0.0035, 0.01, 0.02, 0.05, 0.25, 0.0, -1.0, 0.7, 3e-6], np.float32)
+    n_skip = n_keep = 0
+    for err in errs:
+        e = float(np.float32(0.0010008)) if err == 0 else float(err)
+        rd = np.unique(np.concatenate([rng.integers(0, 1 << 24, 3000), np.arange(0, 400), [(1 << 24) - 1, 1 << 24, 1 << 25]]))
+        for d in rd:
+            m = d * e
+            for k in {0, 1, int(m) - 1, int(m), int(m) + 1, int(m) + 2, int(m * 0.999999), int(m * 1.000001) + 1, (1 << 24) - 1, 1 << 24}:
+                if k < 0:
+                    continue
+                sk = H.ampli_host_prefilter_skip_f32(int(k), int(d), float(err))
+                if sk:
+                    n_skip += 1
+                    assert H.ampli_host_prefilter_nocall(int(k), int(d), float(err)) == 1, (k, d, err)
+                else:
+                    n_keep += 1
+    assert n_skip > 50000 and n_keep > 50000
+    # and it is not vacuous: a count well below the mean is skipped, one above is kept
+    assert H.ampli_host_prefilter_skip_f32(1, 1000, 0.002) == 1 and H.ampli_host_prefilter_skip_f32(3, 1000, 0.002) == 0
