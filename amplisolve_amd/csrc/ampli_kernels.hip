@@ -35,7 +35,8 @@ struct ampli_ctx {
     void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
     size_t queue_items = 0;
     size_t queue_min_items = 0; // ampli_set_queue_items
-    unsigned long long *queue_n = nullptr;
+    unsigned long long *queue_n = nullptr; // two counter arrays, used alternately
+    unsigned queue_parity = 0;
     int n_cu = 256;
 };
 
@@ -887,7 +888,6 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 // LDS (an earlier version) still paid one such loop per wave for a couple of items.  The dense second kernel pays
 // it once per 32 items.
 // ---------------------------------------------------------------------------
-constexpr int PCS_SAMPLES = 16;
 
 struct PcItem { // 32 bytes
     int sample, record, alt_pad;
@@ -897,9 +897,9 @@ struct PcItem { // 32 bytes
 
 __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
-    const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
-    PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
-    int *__restrict__ flags)
+    const int T, const int rows_per_block, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code,
+    const int cov, PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
+    unsigned *__restrict__ mask_words, int *__restrict__ flags)
 {
     const int lane = threadIdx.x & 63;
     const long long R = P + E;
@@ -907,9 +907,26 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const bool valid = r_raw < R;
     const long long r = valid ? r_raw : R - 1;
     const long long p = r < P ? r : (long long)ext_pos[r - P];
-    const int t0 = blockIdx.y * PCS_SAMPLES;
-    const int nt_rows = min(PCS_SAMPLES, T - t0);
+    const int t0 = blockIdx.y * rows_per_block;
+    const int nt_rows = min(rows_per_block, T - t0);
     const int ref = valid ? (int)ref_code[p] : 255;
+
+    // this workgroup's slice of the call mask starts as "no call": rows [t0, t0+nt_rows) x 256 records, whole
+    // words only (R is a multiple of 4 here or the tail word is shared with the next row and zeroed by both).
+    {
+        for (int i = threadIdx.x; i < nt_rows * 64; i += 256) {
+            const int dt = i >> 6, w = i & 63;
+            const long long rec = (long long)blockIdx.x * 256 + (long long)w * 4;
+            if (rec < R) {
+                const size_t byte = (size_t)(t0 + dt) * R + rec;
+                if ((R & 3) == 0) mask_words[byte >> 2] = 0u;
+                else { // unaligned rows: byte stores for this rare shape
+                    unsigned char *mb = (unsigned char *)mask_words;
+                    for (int j = 0; j < 4 && rec + j < R; ++j) mb[byte + j] = 0;
+                }
+            }
+        }
+    }
 
     float te[2][4]; // effective error per strand / nucleotide
 #pragma unroll
@@ -982,9 +999,12 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
     const PcItem *__restrict__ queue, const long long queue_per_shard, const unsigned long long *__restrict__ queue_n,
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const float *__restrict__ thr, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls,
-    const long long capacity, unsigned long long *__restrict__ n_calls)
+    const long long capacity, unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n)
 {
     const long long R = P + E;
+    // the counter array of the NEXT poisson_call (the other half of a double buffer; its last reader, the previous
+    // drain, finished before this kernel started) is reset here, which saves a memset launch per call
+    if (blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) next_queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
     const long long nthreads = (long long)gridDim.x * blockDim.x;
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     // the shards form one flat index space: cum[k] = items in shards < k (clamped to the segment size)
@@ -1276,20 +1296,34 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
             if (hipMalloc(&ctx->queue, want * sizeof(PcItem)) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "queue hipMalloc failed");
             ctx->queue_items = want;
         }
-        if (!ctx->queue_n && hipMalloc((void **)&ctx->queue_n, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS) != hipSuccess)
-            return fail(ctx, AMPLI_E_NOMEM, "queue counter hipMalloc failed");
+        if (!ctx->queue_n) {
+            if (hipMalloc((void **)&ctx->queue_n, 2 * sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS) != hipSuccess)
+                return fail(ctx, AMPLI_E_NOMEM, "queue counter hipMalloc failed");
+            HIP_TRY(ctx, hipMemsetAsync(ctx->queue_n, 0, 2 * sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
+        }
         if (((uintptr_t)d_call_mask & 3) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call_mask must be 4-byte aligned");
         const long long per = (long long)(ctx->queue_items / AMPLI_CALL_SHARDS);
-        HIP_TRY(ctx, hipMemsetAsync(ctx->queue_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(d_call_mask, 0, (size_t)T * R, ctx->stream));
-        dim3 qgrid((unsigned)((R + 255) / 256), (unsigned)((T + PCS_SAMPLES - 1) / PCS_SAMPLES));
+        unsigned long long *qn = ctx->queue_n + (size_t)(ctx->queue_parity & 1) * AMPLI_CALL_COUNTER_WORDS;
+        unsigned long long *qn_next = ctx->queue_n + (size_t)((ctx->queue_parity + 1) & 1) * AMPLI_CALL_COUNTER_WORDS;
+        ctx->queue_parity ^= 1;
+        // rows per workgroup: one balanced wave of workgroups when the panel is small enough, else whole columns
+        const long long tiles = (R + 255) / 256;
+        const long long resident = (long long)ctx->n_cu * 8; // 256-thread workgroups at <= 64 VGPRs
+        long long gy = resident / tiles;
+        if (gy < 1) gy = 1;
+        if (gy > T) gy = T;
+        int rows = (int)((T + gy - 1) / gy);
+        if (rows < 4 && T >= 4) rows = 4; // keep the per-position constants amortised
+        gy = (T + rows - 1) / rows;
+        dim3 qgrid((unsigned)tiles, (unsigned)gy);
         hipLaunchKernelGGL(poisson_stream_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P, (long long)E,
-                           d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, ctx->queue_n, ctx->d_flags);
+                           d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
+                           (unsigned *)d_call_mask, ctx->d_flags);
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, ctx->stream, (const PcItem *)ctx->queue,
-                           per, ctx->queue_n, (const int4 *)d_trecs, (long long)P, (long long)E, d_ext_pos, d_thr,
-                           (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls);
+                           per, qn, (const int4 *)d_trecs, (long long)P, (long long)E, d_ext_pos, d_thr,
+                           (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
         return check_launch(ctx, "poisson_drain_kernel");
     }
     return check_launch(ctx, "poisson_call_kernel");

@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--mode", default="prefilter", choices=["prefilter", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splits", type=int, default=0, help="error_reduce sample splits (0 = auto)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
     return ap.parse_args()
 
 
@@ -159,10 +161,15 @@ def main():
     from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
     from amplisolve_amd.dist import merge_error_table
 
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)  # == local_rank on a full node; ranks share a device only in rehearsals
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = Context(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+    ctx = Context(dev_index)
     if args.splits:
         ctx.set_tuning(args.splits)
     mode = POISSON_PREFILTER if args.mode == "prefilter" else POISSON_FULL
@@ -218,6 +225,26 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if world > 1 and args.check:
+        # every shard regenerated locally and reduced in one pass must equal the merged table, bit for bit
+        allrecs = torch.cat([ctx.synth_fill(P, S, first_sample=k * S, seed=SEED, depth=depth) for k in range(world)])
+        ref = ctx.error_reduce(allrecs, P, 0.002, 100)
+        for name, plane in ref.planes().items():
+            got = acc.planes()[name]
+            if name in ("gm_first", "gm_first_af"):
+                sel = ref.gm_n > 0
+                ok = torch.equal(plane[sel], got[sel])
+            elif name == "gm_rest":
+                sel = ref.gm_n > 1
+                ok = torch.equal(plane[sel], got[sel])
+            else:
+                ok = torch.equal(plane, got)
+            if not ok:
+                raise SystemExit(f"rank {rank}: merged table differs from the single-pass table in plane {name}")
+        del allrecs, ref
+        if rank == 0:
+            print("check: merged accumulator table == single-pass table on every plane", file=sys.stderr)
+        fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
