@@ -277,10 +277,23 @@ def main():
         red_bytes = 32 * P * S + acc_bytes                 # algorithmic bytes of error_reduce per launch
         call_bytes = 32 * P * T + 33 * P + P * T           # poisson_call: records + thresholds/ref + mask
         if t_red >= t_call:
-            dom, dom_ms, dom_bytes = "error_reduce_kernel", t_red, red_bytes
+            dom, dom_ms, dom_bytes = "error_reduce_kernel<true>", t_red, red_bytes
         else:
-            dom, dom_ms, dom_bytes = "poisson_call_kernel", t_call, call_bytes
+            dom, dom_ms, dom_bytes = "poisson_stream_kernel+poisson_drain_kernel", t_call, call_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel from the PMC counters: collected with rocprofv3 --pmc in separate passes of
+        # this same command (tools/collect_profiles.sh) and corrected as MI355X_MICROARCH.md prescribes; committed
+        # under profiles/.  null when the workload is not the profiled one.
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
+        if args.config == "c3" and world == 1 and os.path.exists(pj):
+            try:
+                pm = json.load(open(pj))
+                key = [k for k in pm if dom.split("+")[0].split("<")[0] in k]
+                traffic = sum(pm[k].get("hbm_bytes_per_launch", 0.0) for k in pm
+                              if any(part.split("<")[0] in k for part in dom.split("+"))) or None
+            except Exception:
+                traffic = None
         out = {
             "metric": "position-evaluations/s (error-est + Poisson call)",
             "value": evals / elapsed,
@@ -298,7 +311,8 @@ def main():
                        "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode,
                        "parallelism": f"tumour+normal sample shards x{world}" + ("; RCCL all-reduce + all-gather of the error table" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
+                         "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)" if traffic else None},
             "kernels": {"error_reduce_ms": t_red, "error_reduce_GBs": red_bytes / (t_red * 1e-3) / 1e9,
                         "poisson_call_ms": t_call, "poisson_call_GBs": call_bytes / (t_call * 1e-3) / 1e9,
                         "poisson_call_full_mode_ms": t_call_full,

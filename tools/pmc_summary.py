@@ -8,6 +8,6 @@ for path in sys.argv[1:]:
             k = r["Kernel_Name"].split("(")[0][:40]
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in acc.items():
-            if not any(x in k for x in ("error_reduce", "poisson_call", "finalize", "acc_merge")):
+            if not any(x in k for x in ("error_reduce", "poisson_", "finalize", "acc_merge")):
                 continue
             print(k, {c: round(sum(v) / len(v), 1) for c, v in d.items()}, "n=", len(next(iter(d.values()))))
