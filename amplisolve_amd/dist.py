@@ -55,3 +55,47 @@ def merge_error_table(acc, fold, group=None, gather_buf=None):
         w.wait()
     fold(acc, gather_buf, world)
     return acc
+
+
+class TableMerger:
+    """Asynchronous, double-buffered form of merge_error_table for a pipeline of independent batches.
+
+    start(acc, slot) packs the additive planes of `acc` into ONE float64 buffer (srd/cnt/nrec are exact in a
+    double: < 2^53) and enqueues a single all-reduce plus the all-gather of the germ-max region; finish(...)
+    makes the compute stream wait for them, unpacks and folds.  Between the two calls the caller is free to run
+    the previous batch's finalize + poisson_call and the next batch's error_reduce: the collectives ride on
+    RCCL's own stream over xGMI while the CUs keep streaming HBM.
+    """
+
+    def __init__(self, P: int, world: int, device, fold, group=None):
+        import torch
+
+        self.P, self.world, self.group, self.fold = P, world, group, fold
+        _, self.gm_off, self.gm_bytes = table_regions(P)
+        self.packed = [torch.empty(21 * P, dtype=torch.float64, device=device) for _ in range(2)]
+        self.gathered = [torch.empty(world * self.gm_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
+
+    def start(self, acc, slot: int):
+        import torch.distributed as dist
+
+        P, pk = self.P, self.packed[slot]
+        pk[0:8 * P].copy_(acc.snt.view(-1))
+        pk[8 * P:16 * P].copy_(acc.srd.view(-1))
+        pk[16 * P:20 * P].copy_(acc.cnt.view(-1))
+        pk[20 * P:21 * P].copy_(acc.nrec)
+        w_g = dist.all_gather_into_tensor(self.gathered[slot], acc.buf[self.gm_off: self.gm_off + self.gm_bytes],
+                                          group=self.group, async_op=True)
+        w_r = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return (w_r, w_g)
+
+    def finish(self, acc, slot: int, handle):
+        P, pk = self.P, self.packed[slot]
+        w_r, w_g = handle
+        w_r.wait()
+        acc.snt.view(-1).copy_(pk[0:8 * P])
+        acc.srd.view(-1).copy_(pk[8 * P:16 * P])
+        acc.cnt.view(-1).copy_(pk[16 * P:20 * P])
+        acc.nrec.copy_(pk[20 * P:21 * P])
+        w_g.wait()
+        self.fold(acc, self.gathered[slot], self.world)
+        return acc

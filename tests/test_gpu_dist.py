@@ -1,0 +1,25 @@
+"""N > 1 bench path rehearsed on ONE GPU: two ranks share cuda:0 and talk over gloo (RCCL needs one GPU per rank).
+Exercises exactly the code the driver runs at N = 2/4/8 -- shard generation, the pipelined TableMerger, the
+device-side germ-max fold -- and checks the merged table against a single-pass reduction of all shards."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2])
+def test_bench_multirank_path_on_one_gpu(world):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "3",
+           "--backend", "gloo", "--check", "--config", "c2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "check: merged accumulator table == single-pass table on every plane" in r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
