@@ -116,8 +116,8 @@ class Context:
     def sync(self):
         self._check(self.lib.ampli_sync(self.h))
 
-    def set_tuning(self, reduce_splits: int = 0, general: bool = False):
-        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general)))
+    def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
+        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general) | (groups << 4)))
 
     def set_queue_items(self, items: int):
         self._check(self.lib.ampli_set_queue_items(self.h, items))

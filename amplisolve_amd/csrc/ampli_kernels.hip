@@ -30,6 +30,7 @@ struct ampli_ctx {
     void *ws = nullptr; // workspace for partial accumulator tables
     size_t ws_bytes = 0;
     int reduce_splits = 0; // 0 = auto
+    int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
     void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
@@ -192,7 +193,8 @@ extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, in
 {
     if (!ctx || reduce_sample_splits < 0) return AMPLI_E_INVALID;
     ctx->reduce_splits = reduce_sample_splits;
-    ctx->reduce_general = reduce_general ? 1 : 0;
+    ctx->reduce_general = reduce_general & 1;
+    ctx->reduce_groups = (reduce_general >> 4) & 7; // bits 4-6: lane groups per wave (0 = auto)
     return AMPLI_OK;
 }
 
@@ -477,13 +479,21 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
     const double prod_bw = (double)((float)BW * C); // EE:1599
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
+#if defined(AMPLI_DIAG_NOTHR)
+        if (covok && fw[nt] == -77 && bw[nt] <= lim_bw) {
+#else
         if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
+#endif
             a.sx[0][nt] += fw[nt]; a.sd[0][nt] += FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
             a.sx[1][nt] += bw[nt]; a.sd[1][nt] += BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
             a.cnt[nt] += 1;                                                   // EE:1606
         }
         const int x = fw[nt] + bw[nt];
+#if defined(AMPLI_DIAG_NOGM)
+        if (covok && x == -77) {
+#else
         if (covok && x <= lim_rd) { // EE:1251: float(X)/float(RD) <= 0.05
+#endif
             if (a.gn[nt] == 0) {    // first qualifying record: its AF is dropped by the reference (EE:1258-1261)
                 a.gfx[nt] = x; a.gfd[nt] = RD; a.gfi[nt] = sample;
             } else if (mul24x24(x, a.gbd[nt]) > mul24x24(a.gbx[nt], RD)) { // x/RD > best: EE:1266 (ties keep the value)
@@ -503,13 +513,7 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
 // split for acc_merge_kernel.
 // ---------------------------------------------------------------------------
 constexpr int RED_WAVES = 4;
-#ifndef AMPLI_RED_UNROLL
-#define AMPLI_RED_UNROLL 1
-#endif
-#ifndef AMPLI_RED_PINGPONG
-#define AMPLI_RED_PINGPONG 0
-#endif
-constexpr int RED_UNROLL = AMPLI_RED_UNROLL;
+
 
 __device__ __forceinline__ void fast_to_lane(const FastAcc &f, LaneAcc &a)
 {
@@ -529,28 +533,81 @@ __device__ __forceinline__ void fast_to_lane(const FastAcc &f, LaneAcc &a)
     a.nrec = f.nrec;
 }
 
+// LDS staging for the ordered combine of the 4 wave partials: a two-level tree (waves 1,3 -> 0,2; then 2 -> 0)
+// needs room for two partials only (27 KB instead of 40 KB: four workgroups per CU instead of three).
 struct RedShared {
-    double snt[RED_WAVES - 1][8][64];
-    long long srd[RED_WAVES - 1][8][64];
-    int ints[RED_WAVES - 1][13][64];
-    float flts[RED_WAVES - 1][8][64];
+    double snt[2][8][64];
+    long long srd[2][8][64];
+    int ints[2][13][64];
+    float flts[2][8][64];
 };
 
-template <bool FAST>
+__device__ __forceinline__ void lds_put(RedShared &sh, const int slot, const int lane, const LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        sh.snt[slot][nt][lane] = a.snt[0][nt]; sh.snt[slot][4 + nt][lane] = a.snt[1][nt];
+        sh.srd[slot][nt][lane] = a.srd[0][nt]; sh.srd[slot][4 + nt][lane] = a.srd[1][nt];
+        sh.ints[slot][nt][lane] = a.cnt[nt];
+        sh.ints[slot][4 + nt][lane] = a.gm_n[nt];
+        sh.ints[slot][8 + nt][lane] = a.gm_first[nt];
+        sh.flts[slot][nt][lane] = a.gm_first_af[nt];
+        sh.flts[slot][4 + nt][lane] = a.gm_rest[nt];
+    }
+    sh.ints[slot][12][lane] = a.nrec;
+}
+
+__device__ __forceinline__ void lds_get(const RedShared &sh, const int slot, const int lane, LaneAcc &b)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        b.snt[0][nt] = sh.snt[slot][nt][lane]; b.snt[1][nt] = sh.snt[slot][4 + nt][lane];
+        b.srd[0][nt] = sh.srd[slot][nt][lane]; b.srd[1][nt] = sh.srd[slot][4 + nt][lane];
+        b.cnt[nt] = sh.ints[slot][nt][lane];
+        b.gm_n[nt] = sh.ints[slot][4 + nt][lane];
+        b.gm_first[nt] = sh.ints[slot][8 + nt][lane];
+        b.gm_first_af[nt] = sh.flts[slot][nt][lane];
+        b.gm_rest[nt] = sh.flts[slot][4 + nt][lane];
+    }
+    b.nrec = sh.ints[slot][12][lane];
+}
+
+__device__ __forceinline__ void lane_acc_shfl_down(const LaneAcc &a, LaneAcc &b, const int off)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        b.snt[0][nt] = __shfl_down(a.snt[0][nt], off); b.snt[1][nt] = __shfl_down(a.snt[1][nt], off);
+        b.srd[0][nt] = __shfl_down(a.srd[0][nt], off); b.srd[1][nt] = __shfl_down(a.srd[1][nt], off);
+        b.cnt[nt] = __shfl_down(a.cnt[nt], off);
+        b.gm_n[nt] = __shfl_down(a.gm_n[nt], off);
+        b.gm_first[nt] = __shfl_down(a.gm_first[nt], off);
+        b.gm_first_af[nt] = __shfl_down(a.gm_first_af[nt], off);
+        b.gm_rest[nt] = __shfl_down(a.gm_rest[nt], off);
+    }
+    b.nrec = __shfl_down(a.nrec, off);
+}
+
+// G lane groups per wave: a wave covers 64/G positions and G consecutive sample chunks (group g of wave w of
+// workgroup (tile, split) owns chunk ((split*4 + w)*G + g)).  More, shorter waves for the same panel: the launch
+// then runs several balanced rounds instead of one and a half long ones (the fixed ~24 us of ramp + tail measured
+// at G = 1 shrinks with the wave lifetime).  A lane group still reads >= 512 contiguous bytes per sample row.
+template <bool FAST, int G>
 __global__ __launch_bounds__(256) void error_reduce_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
     const size_t part_stride, const size_t o0, const size_t o1, const size_t o2, const size_t o3, const size_t o4,
     const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags)
 {
+    constexpr int W = 64 / G; // positions per wave
     __shared__ RedShared sh;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long long p_raw = (long long)blockIdx.x * 64 + lane;
+    const int group = lane / W;
+    const long long p_raw = (long long)blockIdx.x * W + (lane % W);
     const bool valid = p_raw < P;
     const long long p = valid ? p_raw : P - 1; // clamp: out-of-range lanes re-read the last position, never store
     const long long R = P + E;
-    const int chunk = blockIdx.y * RED_WAVES + wave;
+    const int chunk = (blockIdx.y * RED_WAVES + wave) * G + group;
     const int s0 = min(S, chunk * chunk_len);
     const int s1 = min(S, s0 + chunk_len);
 
@@ -563,89 +620,60 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     if (E > 0) { e0 = dup_off[p]; e1 = dup_off[p + 1]; }
     const bool any_dup = E > 0 && __any(e1 > e0);
 
-    // Two register batches of RED_UNROLL sample rows, ping-pong: one is being consumed while the loads of the
-    // other are in flight (no copies between them).
-    int4 a0[RED_UNROLL], a1[RED_UNROLL], b0[RED_UNROLL], b1[RED_UNROLL];
-    auto load_batch = [&](int4 (&x0)[RED_UNROLL], int4 (&x1)[RED_UNROLL], const int s) {
-#pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) {
-            const int sn = min(s + u, S - 1); // clamped rows are loaded but never visited
-            const int4 *q = recs + ((size_t)sn * R + p) * 2;
-            x0[u] = q[0];
-            x1[u] = q[1];
+    // one sample row in registers + the next one in flight; every lane group walks its own chunk, the trip count
+    // (chunk_len) is wave-uniform and rows past a group's chunk are loaded clamped and not visited
+    const size_t row_stride = (size_t)R * 2;
+    const int4 *q = recs + ((size_t)min(s0, S - 1) * R + p) * 2;
+    int4 n0 = q[0], n1 = q[1];
+    for (int i = 0; i < chunk_len; ++i) {
+        const int s = s0 + i;
+        const int4 c0 = n0, c1 = n1;
+        if (i + 1 < chunk_len) { // prefetch while this row is consumed
+            if (s + 1 < S) q += row_stride;
+            n0 = q[0];
+            n1 = q[1];
         }
-    };
-    auto visit_batch = [&](const int4 (&x0)[RED_UNROLL], const int4 (&x1)[RED_UNROLL], const int s) {
-#pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) {
-            if (s + u < s1) {
-                if (FAST) visit_fast(f, x0[u], x1[u], first_sample + s + u, C, cov);
-                else visit_record(a, x0[u], x1[u], first_sample + s + u, C, cov);
-                if (any_dup) { // extras of this position in the same sample, in file order
-                    for (unsigned e = e0; e < e1; ++e) {
-                        const int4 *q = recs + ((size_t)(s + u) * R + (size_t)P + e) * 2;
-                        if (FAST) visit_fast(f, q[0], q[1], first_sample + s + u, C, cov);
-                        else visit_record(a, q[0], q[1], first_sample + s + u, C, cov);
-                    }
+        if (s < s1) {
+            if (FAST) visit_fast(f, c0, c1, first_sample + s, C, cov);
+            else visit_record(a, c0, c1, first_sample + s, C, cov);
+            if (any_dup) { // extras of this position in the same sample, in file order
+                for (unsigned e = e0; e < e1; ++e) {
+                    const int4 *x = recs + ((size_t)s * R + (size_t)P + e) * 2;
+                    if (FAST) visit_fast(f, x[0], x[1], first_sample + s, C, cov);
+                    else visit_record(a, x[0], x[1], first_sample + s, C, cov);
                 }
             }
         }
-    };
-    load_batch(a0, a1, s0);
-#if AMPLI_RED_PINGPONG
-    for (int s = s0; s < s1; s += 2 * RED_UNROLL) {
-        if (s + RED_UNROLL < s1) load_batch(b0, b1, s + RED_UNROLL);
-        visit_batch(a0, a1, s);
-        if (s + 2 * RED_UNROLL < s1) load_batch(a0, a1, s + 2 * RED_UNROLL);
-        if (s + RED_UNROLL < s1) visit_batch(b0, b1, s + RED_UNROLL);
     }
-#else
-    for (int s = s0; s < s1; s += RED_UNROLL) {
-#pragma unroll
-        for (int u = 0; u < RED_UNROLL; ++u) { b0[u] = a0[u]; b1[u] = a1[u]; }
-        if (s + RED_UNROLL < s1) load_batch(a0, a1, s + RED_UNROLL); // prefetch while this batch is consumed
-        visit_batch(b0, b1, s);
-    }
-#endif
     if (FAST) {
         if (f.bad || f.nrec > FAST_MAX_RECORDS) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
         fast_to_lane(f, a);
     }
 
-    // ordered combine of the 4 wave partials through LDS (wave order = sample order)
-    if (wave > 0) {
-        const int w = wave - 1;
+    // ordered combine, stage 1: the G lane groups of this wave (group order = sample order), in registers
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            sh.snt[w][nt][lane] = a.snt[0][nt]; sh.snt[w][4 + nt][lane] = a.snt[1][nt];
-            sh.srd[w][nt][lane] = a.srd[0][nt]; sh.srd[w][4 + nt][lane] = a.srd[1][nt];
-            sh.ints[w][nt][lane] = a.cnt[nt];
-            sh.ints[w][4 + nt][lane] = a.gm_n[nt];
-            sh.ints[w][8 + nt][lane] = a.gm_first[nt];
-            sh.flts[w][nt][lane] = a.gm_first_af[nt];
-            sh.flts[w][4 + nt][lane] = a.gm_rest[nt];
-        }
-        sh.ints[w][12][lane] = a.nrec;
+    for (int off = W; off < 64; off <<= 1) {
+        LaneAcc b;
+        lane_acc_shfl_down(a, b, off);
+        if ((group % (2 * off / W)) == 0) lane_acc_merge(a, b);
+    }
+    // stage 2: the 4 waves through LDS, a tree over adjacent chunks (wave order = sample order):
+    // waves 1,3 hand over to 0,2; then wave 2 hands over to wave 0
+    if (wave & 1) lds_put(sh, wave >> 1, lane, a);
+    __syncthreads();
+    if (!(wave & 1)) {
+        LaneAcc b;
+        lds_get(sh, wave >> 1, lane, b);
+        lane_acc_merge(a, b);
     }
     __syncthreads();
+    if (wave == 2) lds_put(sh, 0, lane, a);
+    __syncthreads();
     if (wave == 0) {
-#pragma unroll 1
-        for (int w = 0; w < RED_WAVES - 1; ++w) {
-            LaneAcc b;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                b.snt[0][nt] = sh.snt[w][nt][lane]; b.snt[1][nt] = sh.snt[w][4 + nt][lane];
-                b.srd[0][nt] = sh.srd[w][nt][lane]; b.srd[1][nt] = sh.srd[w][4 + nt][lane];
-                b.cnt[nt] = sh.ints[w][nt][lane];
-                b.gm_n[nt] = sh.ints[w][4 + nt][lane];
-                b.gm_first[nt] = sh.ints[w][8 + nt][lane];
-                b.gm_first_af[nt] = sh.flts[w][nt][lane];
-                b.gm_rest[nt] = sh.flts[w][4 + nt][lane];
-            }
-            b.nrec = sh.ints[w][12][lane];
-            lane_acc_merge(a, b);
-        }
-        if (valid) {
+        LaneAcc b;
+        lds_get(sh, 0, lane, b);
+        lane_acc_merge(a, b);
+        if (valid && group == 0) {
             const AccPtrs t = acc_at(out_base + (size_t)blockIdx.y * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7);
             lane_acc_store(t, P, p_raw, a);
         }
@@ -1152,23 +1180,31 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
     if (((uintptr_t)d_recs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-    const long long tiles = (P + 63) / 64;
-    // sample splits: enough waves to fill the chip (>= ~16 waves per CU), each with >= 8 samples
+    // lane groups per wave: only for panels too small to fill the chip with 64-position waves (measured on c3:
+    // G = 2 / 4 cost 6 % / 11 % -- the narrower per-row segments outweigh the shorter tail)
+    const long long resident_waves = (long long)ctx->n_cu * 16;
+    int G = ctx->reduce_groups;
+    if (G != 1 && G != 2 && G != 4) {
+        G = 1;
+        while (G < 4 && ((P + 64 / G - 1) / (64 / G)) * RED_WAVES < resident_waves && S / (RED_WAVES * 2 * G) >= 8) G *= 2;
+    }
+    const long long tiles = (P + 64 / G - 1) / (64 / G);
+    // sample splits: enough waves to fill the chip (>= ~24 waves per CU), each lane group with >= 8 samples
     int splits = ctx->reduce_splits;
     if (splits <= 0) {
         const long long want_waves = (long long)ctx->n_cu * 24;
         splits = (int)((want_waves + tiles * RED_WAVES - 1) / (tiles * RED_WAVES));
-        const int max_splits = (S + RED_WAVES * 8 - 1) / (RED_WAVES * 8);
+        const int max_splits = (S + RED_WAVES * G * 8 - 1) / (RED_WAVES * G * 8);
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
     if (splits > S) splits = S;
     const bool fast = !ctx->reduce_general;
-    if (fast) { // int32 partial sums: a wave takes at most FAST_MAX_CHUNK samples
-        const int need = (S + RED_WAVES * FAST_MAX_CHUNK - 1) / (RED_WAVES * FAST_MAX_CHUNK);
+    if (fast) { // int32 partial sums: a lane takes at most FAST_MAX_CHUNK samples
+        const int need = (S + RED_WAVES * G * FAST_MAX_CHUNK - 1) / (RED_WAVES * G * FAST_MAX_CHUNK);
         if (splits < need) splits = need;
     }
-    const int chunks = splits * RED_WAVES;
+    const int chunks = splits * RED_WAVES * G;
     const int chunk_len = (S + chunks - 1) / chunks;
 
     size_t off[9];
@@ -1182,14 +1218,20 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
         stride = off[8];
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (fast)
-        hipLaunchKernelGGL(error_reduce_kernel<true>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P,
-                           (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],
-                           off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags);
-    else
-        hipLaunchKernelGGL(error_reduce_kernel<false>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P,
-                           (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],
-                           off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags);
+#define AMPLI_LAUNCH_REDUCE(FASTV, GV)                                                                                       \
+    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, \
+                       (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],  \
+                       off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags)
+    if (fast) {
+        if (G == 4) AMPLI_LAUNCH_REDUCE(true, 4);
+        else if (G == 2) AMPLI_LAUNCH_REDUCE(true, 2);
+        else AMPLI_LAUNCH_REDUCE(true, 1);
+    } else {
+        if (G == 4) AMPLI_LAUNCH_REDUCE(false, 4);
+        else if (G == 2) AMPLI_LAUNCH_REDUCE(false, 2);
+        else AMPLI_LAUNCH_REDUCE(false, 1);
+    }
+#undef AMPLI_LAUNCH_REDUCE
     int rc = check_launch(ctx, "error_reduce_kernel");
     if (rc) return rc;
     if (splits > 1) {

@@ -108,7 +108,7 @@ inline bool parse_int(const char *&p, const char *e, int64_t &v)
 
 // One file.  Columns: chr pos dbsnp MAF ref alt A C G T RD Ars Crs Grs Trs (EE:1149, VC:752); the first line
 // is the header (EE:1113, VC:721).  fw = X - Xrs (EE:1155-1158).
-void parse_file(const Panel &panel, const std::string &path, bool keep_line, bool print_irregular, FileResult &out)
+void parse_file(const Panel &panel, const std::string &path, bool keep_line, FileResult &out)
 {
     const int64_t P = panel.P();
     out.main.assign((size_t)P * 8, 0);
@@ -173,7 +173,6 @@ void parse_file(const Panel &panel, const std::string &path, bool keep_line, boo
                                       (int32_t)v[5], (int32_t)v[6], (int32_t)v[7], (int32_t)v[8]};
                     if (A + C + G + T != RD) { // EE:1178-1181, VC:762-765
                         ++out.n_irregular;
-                        if (print_irregular) std::cout << "malakia paizei edo" << std::endl;
                     }
                     const unsigned k = occ[pi];
                     if (k < 255) occ[pi] = (uint8_t)(k + 1);
@@ -212,16 +211,18 @@ void cohort_load(const Panel &panel, const std::string &dir, const std::string &
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads > S) n_threads = S;
     if (n_threads < 1) n_threads = 1;
-    if (print_irregular) n_threads = 1; // keep the reference's stdout order
     std::atomic<int> next{0};
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t)
         th.emplace_back([&] {
-            for (int s; (s = next.fetch_add(1)) < S;) parse_file(panel, out.paths[s], keep_line_no, print_irregular, res[s]);
+            for (int s; (s = next.fetch_add(1)) < S;) parse_file(panel, out.paths[s], keep_line_no, res[s]);
         });
     for (auto &t : th) t.join();
     for (int s = 0; s < S; ++s)
         if (!res[s].error.empty()) throw Error{AMPLI_E_INVALID, res[s].error};
+    if (print_irregular) // the reference's own message, once per offending line (EE:1178-1181, VC:762-765)
+        for (int s = 0; s < S; ++s)
+            for (int64_t i = 0; i < res[s].n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl;
 
     // extra occurrences: slot layout from the largest multiplicity seen in any file
     std::vector<uint32_t> mult((size_t)P, 0);

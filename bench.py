@@ -45,6 +45,7 @@ def parse_args():
     ap.add_argument("--mode", default="prefilter", choices=["prefilter", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splits", type=int, default=0, help="error_reduce sample splits (0 = auto)")
+    ap.add_argument("--groups", type=int, default=0, help="error_reduce lane groups per wave (0 = auto, 1, 2, 4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
     return ap.parse_args()
@@ -170,8 +171,8 @@ def main():
         else:
             dist.init_process_group(args.backend)
     ctx = Context(dev_index)
-    if args.splits:
-        ctx.set_tuning(args.splits)
+    if args.splits or args.groups:
+        ctx.set_tuning(args.splits, groups=args.groups)
     mode = POISSON_PREFILTER if args.mode == "prefilter" else POISSON_FULL
 
     P, S, T, depth = cfg["P"], cfg["S"], cfg["T"], cfg["depth"]

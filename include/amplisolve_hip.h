@@ -225,7 +225,8 @@ int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t see
 
 /* tuning knobs.  reduce_sample_splits: 0 = automatic.  reduce_general: 0 = the fast error_reduce kernel
  * (valid while every strand depth is < 2^22; it raises AMPLI_FLAG_RERUN_GENERAL otherwise), 1 = the literal
- * kernel that follows the reference operation by operation for any depth (slower). */
+ * kernel that follows the reference operation by operation for any depth (slower).  Bits 4-6 of reduce_general
+ * force the number of lane groups per wave (1, 2 or 4; 0 = automatic). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general);
 
 /* Minimum capacity (items of 32 B) of the prefilter queue of ampli_poisson_call; default T*R/4, at least 65536. */

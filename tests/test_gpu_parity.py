@@ -52,15 +52,17 @@ def test_synth_device_matches_host(ctx):
     assert np.array_equal(ctx.synth_ref(777).cpu().numpy(), synth_ref(777))
 
 
+@pytest.mark.parametrize("groups", [0, 1, 2, 4])
 @pytest.mark.parametrize("P,S,splits", [(1, 1, 0), (63, 3, 0), (64, 4, 1), (65, 5, 2), (1000, 32, 0), (1000, 33, 3),
-                                        (4097, 37, 0), (10000, 32, 0)])
-def test_error_reduce_synthetic(ctx, P, S, splits):
+                                        (4097, 37, 0), (10000, 32, 0), (777, 130, 0), (15, 300, 2)])
+def test_error_reduce_synthetic(ctx, P, S, splits, groups):
     recs = synth_recs(P, S)
     ref = orc.error_reduce(recs, P, 0.002, 100)
     assert ref["order_sensitive"] == 0
-    ctx.set_tuning(splits)
+    ctx.set_tuning(splits, groups=groups)
     acc = ctx.error_reduce(_t(recs), P, 0.002, 100)
     ctx.set_tuning(0)
+    assert ctx.flags() == 0
     assert_acc_equal(acc, ref)
     fin = ctx.error_finalize(acc, 0.002, 100)
     assert_final_equal(fin, orc.error_finalize(ref))
@@ -87,8 +89,8 @@ def test_error_reduce_general_kernel_synthetic(ctx, P, S, splits):
     """The literal kernel (reference operation order, any depth) and the fast kernel agree with the oracle."""
     recs = synth_recs(P, S)
     ref = orc.error_reduce(recs, P, 0.002, 100)
-    for general in (True, False):
-        ctx.set_tuning(splits, general=general)
+    for general, groups in ((True, 1), (True, 4), (False, 2), (False, 0)):
+        ctx.set_tuning(splits, general=general, groups=groups)
         acc = ctx.error_reduce(_t(recs), P, 0.002, 100)
         ctx.set_tuning(0)
         assert_acc_equal(acc, ref)
@@ -141,8 +143,12 @@ def test_error_reduce_with_extra_occurrences(ctx):
     extra = edge_case_recs(E, S, rng)
     recs = np.concatenate([base, extra], axis=1)
     ref = orc.error_reduce(recs, P, 0.002, 100, E=E, dup_off=dup_off)
-    acc = ctx.error_reduce(_t(recs), P, 0.002, 100, E=E, dup_off=_t(dup_off))
-    assert_acc_equal(acc, ref)
+    for groups in (1, 2, 4):
+        for general in (False, True):
+            ctx.set_tuning(0, general=general, groups=groups)
+            acc = ctx.error_reduce(_t(recs), P, 0.002, 100, E=E, dup_off=_t(dup_off))
+            ctx.set_tuning(0)
+            assert_acc_equal(acc, ref)
     assert_final_equal(ctx.error_finalize(acc), orc.error_finalize(ref))
 
 
@@ -322,3 +328,38 @@ def test_full_size_properties(ctx):
     assert n_calls == bits and n_calls > 0
     exp = orc.poisson_call(trecs[:4, sl].cpu().numpy(), 900, fin.thr[:, :, sl].cpu().numpy(), refc[sl].cpu().numpy(), 100, dense=False)
     assert np.array_equal(pre["call_mask"][:4, sl].cpu().numpy(), exp["call_mask"])
+
+
+def test_deep_coverage_stress_config5_shape(ctx):
+    """BASELINE config 5 shape at reduced P: depth 50 000x, 256 normals.  Sums are ~25x larger than at config 3:
+    the exactness envelope must still hold (flag 0) and a slice must match the oracle bit for bit."""
+    import torch
+
+    P, S, T, depth = 150_000, 256, 8, 50_000
+    recs = ctx.synth_fill(P, S, depth=depth)
+    acc = ctx.error_reduce(recs, P)
+    assert ctx.flags() == 0
+    fin = ctx.error_finalize(acc)
+    assert int(fin.flags.item()) == 0
+    sl = slice(77_000, 77_700)
+    sub = recs[:, sl].cpu().numpy()
+    ref = orc.error_reduce(sub, 700)
+    assert ref["order_sensitive"] == 0
+    assert np.array_equal(acc.snt[:, :, sl].cpu().numpy(), ref["snt"])
+    assert np.array_equal(acc.srd[:, :, sl].cpu().numpy(), ref["srd"])
+    assert np.array_equal(acc.cnt[:, sl].cpu().numpy(), ref["cnt"])
+    reff = orc.error_finalize(ref)
+    assert np.array_equal(fin.thr[:, :, sl].cpu().numpy().view(np.int32), reff["thr"].view(np.int32))
+    m = reff["germ_present"] > 0
+    assert np.array_equal(fin.germ_val[:, sl].cpu().numpy()[m].astype(np.float64), reff["germ_val"][m])
+    trecs = ctx.synth_fill(P, T, depth=depth, tumour=True)
+    refc = ctx.synth_ref(P)
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    pre = ctx.poisson_call(trecs, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 20)
+    assert ctx.flags() == 0
+    full = ctx.poisson_call(trecs, P, fin.thr, refc, 100, mode=POISSON_FULL)
+    assert torch.equal(pre["call_mask"], full["call_mask"])
+    exp = orc.poisson_call(trecs[:, sl].cpu().numpy(), 700, fin.thr[:, :, sl].cpu().numpy(), refc[sl].cpu().numpy(), 100, dense=False)
+    assert np.array_equal(pre["call_mask"][:, sl].cpu().numpy(), exp["call_mask"])
+    assert ctx.n_calls_total(pre) > 0
