@@ -159,6 +159,32 @@ class Context:
                                                 C_value, cov, C.byref(acc.struct)))
         return acc
 
+    def _new_error_table(self, P: int) -> ErrorTable:
+        import torch
+
+        d = self.device
+        return ErrorTable(rate=torch.empty((2, 4, P), dtype=torch.float32, device=d),
+                          code=torch.empty((4, P), dtype=torch.uint8, device=d),
+                          thr=torch.empty((2, 4, P), dtype=torch.float32, device=d),
+                          germ_val=torch.empty((4, P), dtype=torch.float32, device=d),
+                          germ_present=torch.empty((4, P), dtype=torch.uint8, device=d),
+                          flags=torch.zeros((1,), dtype=torch.int32, device=d))
+
+    def error_estimate(self, recs, P: int, C_value: float = 0.002, cov: int = 100, E: int = 0, dup_off=None,
+                       acc: Acc | None = None, out: ErrorTable | None = None) -> ErrorTable:
+        """Fused error_reduce + error_finalize (ampli_error_estimate); acc optional."""
+        import torch
+
+        assert recs.dtype == torch.int32 and recs.is_cuda and recs.is_contiguous()
+        S = recs.shape[0]
+        assert recs.numel() == S * (P + E) * 8
+        if out is None:
+            out = self._new_error_table(P)
+        self._check(self.lib.ampli_error_estimate(self.h, _ptr(recs), P, E, _ptr(dup_off), S, C_value, cov,
+                                                  C.byref(acc.struct) if acc is not None else None, _ptr(out.rate), _ptr(out.code),
+                                                  _ptr(out.thr), _ptr(out.germ_val), _ptr(out.germ_present), _ptr(out.flags)))
+        return out
+
     def acc_merge(self, parts: list[Acc], dst: Acc | None = None) -> Acc:
         if dst is None:
             dst = self.new_acc(parts[0].P)
@@ -181,13 +207,7 @@ class Context:
 
         P = acc.P
         if out is None:
-            d = self.device
-            out = ErrorTable(rate=torch.empty((2, 4, P), dtype=torch.float32, device=d),
-                             code=torch.empty((4, P), dtype=torch.uint8, device=d),
-                             thr=torch.empty((2, 4, P), dtype=torch.float32, device=d),
-                             germ_val=torch.empty((4, P), dtype=torch.float32, device=d),
-                             germ_present=torch.empty((4, P), dtype=torch.uint8, device=d),
-                             flags=torch.zeros((1,), dtype=torch.int32, device=d))
+            out = self._new_error_table(P)
         self._check(self.lib.ampli_error_finalize(self.h, C.byref(acc.struct), C_value, cov, _ptr(out.rate), _ptr(out.code),
                                                   _ptr(out.thr), _ptr(out.germ_val), _ptr(out.germ_present), _ptr(out.flags)))
         return out

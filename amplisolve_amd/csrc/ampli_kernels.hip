@@ -412,6 +412,58 @@ __device__ __forceinline__ void lane_acc_load(const AccPtrs &t, long long P, lon
 }
 
 // ---------------------------------------------------------------------------
+// finalize of one position from its merged LaneAcc: quorum, rates, NaN code, the table text round trip and the
+// Germ_Max sentinel rule (EE:1659-1714 + clones, EE:1260/1318/1374/1431, EE:1704 -> VC:889-890, EE:2680-2684).
+// Shared by error_finalize_kernel and by the fused epilogue of error_reduce_kernel.
+// ---------------------------------------------------------------------------
+struct FinOut {
+    float *rate; unsigned char *code; float *thr; float *germ_val; unsigned char *germ_present; int *flags;
+};
+
+__device__ __forceinline__ void finalize_lane(const LaneAcc &a, const long long P, const long long p, const float C,
+                                              const int cov, const FinOut &o)
+{
+    // exactness envelope of the double sums: every addend is a multiple of ulp(float(cov)*C) and the
+    // running sum must stay below 2^52 such ulps
+    const float pmin = (float)cov * C;
+    int ex;
+    (void)frexpf(pmin > 0 ? pmin : 1.0f, &ex);
+    const double limit = ldexp(1.0, ex - 24) * 9007199254740992.0 * 0.5;
+    bool bad = false;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const long long i = nt * P + p, ifw = (0 * 4 + nt) * P + p, ibw = (1 * 4 + nt) * P + p;
+        const double sfw = a.snt[0][nt], sbw = a.snt[1][nt];
+        bad |= !(sfw < limit) || !(sbw < limit);
+        float r_fw = 0.0f, r_bw = 0.0f;
+        unsigned char c;
+        if ((double)a.cnt[nt] < 0.338 * (double)a.nrec) { // EE:1659
+            c = 1;
+        } else {
+            r_fw = (float)sfw / (float)(double)a.srd[0][nt]; // EE:1679
+            r_bw = (float)sbw / (float)(double)a.srd[1][nt]; // EE:1680
+            if (isnan(r_fw) || isnan(r_bw)) { c = 2; r_fw = 0.0f; r_bw = 0.0f; } // EE:1682
+            else c = 0;
+        }
+        o.code[i] = c;
+        o.rate[ifw] = r_fw;
+        o.rate[ibw] = r_bw;
+        if (o.thr) {
+            o.thr[ifw] = c ? 0.01f : ampli_text_roundtrip(r_fw); // EE:2680-2684 / EE:1704 -> VC:889-890
+            o.thr[ibw] = c ? 0.01f : ampli_text_roundtrip(r_bw);
+        }
+        if (o.germ_val) {
+            const int n = a.gm_n[nt];
+            float v = (nt == 0) ? -888.0f : 0.0f; // EE:1260 / EE:1318,1374,1431
+            if (n > 1) { const float r = a.gm_rest[nt]; if (v <= r) v = r; }
+            o.germ_val[i] = n ? v : 0.0f;
+            if (o.germ_present) o.germ_present[i] = n ? 1 : 0;
+        }
+    }
+    if (bad && o.flags) atomicOr(o.flags, 1);
+}
+
+// ---------------------------------------------------------------------------
 // Fast per-lane state (the shipped inner loop).  Same results as LaneAcc /
 // visit_record, fewer instructions per record:
 //   * the qualifying sums are kept as an integer part (sum of X, sum of depth,
@@ -596,7 +648,7 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
     const size_t part_stride, const size_t o0, const size_t o1, const size_t o2, const size_t o3, const size_t o4,
-    const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags)
+    const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags, const FinOut fin)
 {
     constexpr int W = 64 / G; // positions per wave
     __shared__ RedShared sh;
@@ -674,8 +726,13 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
         lds_get(sh, 0, lane, b);
         lane_acc_merge(a, b);
         if (valid && group == 0) {
-            const AccPtrs t = acc_at(out_base + (size_t)blockIdx.y * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7);
-            lane_acc_store(t, P, p_raw, a);
+            if (out_base) {
+                const AccPtrs t = acc_at(out_base + (size_t)blockIdx.y * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7);
+                lane_acc_store(t, P, p_raw, a);
+            }
+            // fused epilogue (single split only): the merged state is in registers, finalize it here and spare the
+            // table round trip through HBM plus a launch
+            if (fin.rate) finalize_lane(a, P, p_raw, C, cov, fin);
         }
     }
 }
@@ -747,54 +804,15 @@ __global__ __launch_bounds__(256) void gm_merge_kernel(int *gm_n, int *gm_first,
 // ---------------------------------------------------------------------------
 // error_finalize
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void error_finalize_kernel(AccPtrs t, const long long P, const float C, const int cov,
-                                                             float *rate, unsigned char *code, float *thr,
-                                                             float *germ_val, unsigned char *germ_present, int *flags)
+__global__ __launch_bounds__(256) void error_finalize_kernel(AccPtrs t, const long long P, const float C, const int cov, FinOut o)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
-    const int nrec = t.nrec[p];
-    // exactness envelope of the double sums: every addend is a multiple of
-    // ulp(float(cov)*C) and the running sum must stay below 2^53 ulps.
-    const float pmin = (float)cov * C;
-    int ex;
-    (void)frexpf(pmin > 0 ? pmin : 1.0f, &ex);           // pmin = f * 2^ex, f in [0.5,1)
-    const double ulp = ldexp(1.0, ex - 24);              // lsb of an fp32 value of that magnitude
-    const double limit = ulp * 9007199254740992.0 * 0.5; // 2^52 ulps
-    bool bad = false;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const long long i = nt * P + p, ifw = (0 * 4 + nt) * P + p, ibw = (1 * 4 + nt) * P + p;
-        const int cnt = t.cnt[i];
-        const double sfw = t.snt[ifw], sbw = t.snt[ibw];
-        bad |= !(sfw < limit) || !(sbw < limit);
-        float r_fw = 0.0f, r_bw = 0.0f;
-        unsigned char c;
-        if ((double)cnt < 0.338 * (double)nrec) { // EE:1659
-            c = 1;
-        } else {
-            r_fw = (float)sfw / (float)(double)t.srd[ifw]; // EE:1679
-            r_bw = (float)sbw / (float)(double)t.srd[ibw]; // EE:1680
-            if (isnan(r_fw) || isnan(r_bw)) { c = 2; r_fw = 0.0f; r_bw = 0.0f; } // EE:1682
-            else c = 0;
-        }
-        code[i] = c;
-        rate[ifw] = r_fw;
-        rate[ibw] = r_bw;
-        if (thr) {
-            thr[ifw] = c ? 0.01f : ampli_text_roundtrip(r_fw); // EE:2680-2684 / EE:1704 -> VC:889-890
-            thr[ibw] = c ? 0.01f : ampli_text_roundtrip(r_bw);
-        }
-        if (germ_val) {
-            const int n = t.gm_n[i];
-            float v = (nt == 0) ? -888.0f : 0.0f; // EE:1260 / EE:1318,1374,1431
-            if (n > 1) { const float r = t.gm_rest[i]; if (v <= r) v = r; }
-            germ_val[i] = n ? v : 0.0f;
-            if (germ_present) germ_present[i] = n ? 1 : 0;
-        }
-    }
-    if (bad && flags) atomicOr(flags, 1);
+    LaneAcc a;
+    lane_acc_load(t, P, p, a);
+    finalize_lane(a, P, p, C, cov, o);
 }
+
 
 // ---------------------------------------------------------------------------
 // poisson_call: one lane per record, SAMPLES_PER_BLOCK tumour samples per
@@ -927,10 +945,14 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const int rows_per_block, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code,
     const int cov, PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
-    unsigned *__restrict__ mask_words, int *__restrict__ flags)
+    unsigned *__restrict__ mask_words, int *__restrict__ flags, unsigned long long *__restrict__ n_calls)
 {
     const int lane = threadIdx.x & 63;
     const long long R = P + E;
+    // the call-list counters are reset here: only the drain kernel, which starts after this one has finished,
+    // appends to the list
+    if (n_calls && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < AMPLI_CALL_SHARDS)
+        n_calls[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
     const long long r_raw = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool valid = r_raw < R;
     const long long r = valid ? r_raw : R - 1;
@@ -1170,11 +1192,20 @@ static AccPtrs to_ptrs(const ampli_acc_table *t)
     return a;
 }
 
-extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
-                                  int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc)
+static int launch_finalize(ampli_ctx *ctx, const AccPtrs &t, long long P, float C, int cov, const FinOut &fo)
+{
+    hipLaunchKernelGGL(error_finalize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, t, P, C, cov, fo);
+    return check_launch(ctx, "error_finalize_kernel");
+}
+
+// reduce (+ optional fused finalize).  d_acc may be NULL when fin.rate is set (the table is then not materialised
+// unless the sample axis has to be split across workgroups).
+static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                             int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc,
+                             const FinOut &fin)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || !acc_is_bound(d_acc) || d_acc->P != P)
+    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate))
         return fail(ctx, AMPLI_E_INVALID, "error_reduce: bad argument (P,S>0, cov>=1, table bound with ampli_acc_bind for the same P)");
     if (E > 0 && !d_dup_off) return fail(ctx, AMPLI_E_INVALID, "error_reduce: E > 0 needs dup_off");
     if (((uintptr_t)d_recs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned");
@@ -1209,19 +1240,22 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
 
     size_t off[9];
     acc_offsets(P, off);
-    char *out_base = (char *)d_acc->snt;
+    char *out_base = d_acc ? (char *)d_acc->snt : nullptr;
     size_t stride = 0;
+    FinOut kfin = fin; // what the reduce kernel itself finalises
     if (splits > 1) {
-        int rc = ensure_ws(ctx, off[8] * (size_t)splits);
+        // partial tables, one per split, plus one slot for the merged table when the caller did not ask for it
+        int rc = ensure_ws(ctx, off[8] * (size_t)(splits + 1));
         if (rc) return rc;
         out_base = (char *)ctx->ws;
         stride = off[8];
+        kfin.rate = nullptr;
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                                                                                       \
     hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, \
                        (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],  \
-                       off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags)
+                       off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin)
     if (fast) {
         if (G == 4) AMPLI_LAUNCH_REDUCE(true, 4);
         else if (G == 2) AMPLI_LAUNCH_REDUCE(true, 2);
@@ -1235,12 +1269,40 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
     int rc = check_launch(ctx, "error_reduce_kernel");
     if (rc) return rc;
     if (splits > 1) {
-        hipLaunchKernelGGL(acc_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, (char *)d_acc->snt,
+        char *merged = d_acc ? (char *)d_acc->snt : (char *)ctx->ws + off[8] * (size_t)splits;
+        hipLaunchKernelGGL(acc_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, merged,
                            (const char *)ctx->ws, stride, splits, (long long)P, off[0], off[1], off[2], off[3], off[4], off[5],
                            off[6], off[7]);
         rc = check_launch(ctx, "acc_merge_kernel");
+        if (rc) return rc;
+        if (fin.rate) {
+            AccPtrs t;
+            t.snt = (double *)(merged + off[0]); t.srd = (long long *)(merged + off[1]); t.cnt = (int *)(merged + off[2]);
+            t.nrec = (int *)(merged + off[3]); t.gm_n = (int *)(merged + off[4]); t.gm_first = (int *)(merged + off[5]);
+            t.gm_first_af = (float *)(merged + off[6]); t.gm_rest = (float *)(merged + off[7]);
+            rc = launch_finalize(ctx, t, P, C, cov, fin);
+        }
     }
     return rc;
+}
+
+extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                                  int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc)
+{
+    if (!d_acc) return ctx ? fail(ctx, AMPLI_E_INVALID, "error_reduce: d_acc is required") : AMPLI_E_INVALID;
+    FinOut none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, d_acc, none);
+}
+
+extern "C" int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                                    int32_t S, float C, int32_t cov, const ampli_acc_table *d_acc, float *d_rate,
+                                    uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present,
+                                    int32_t *d_flags)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_rate || !d_code) return fail(ctx, AMPLI_E_INVALID, "error_estimate: rate and code outputs are required");
+    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags};
+    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, 0, C, cov, d_acc, fo);
 }
 
 extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_acc_table *d_parts, int32_t nparts)
@@ -1296,9 +1358,8 @@ extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc
     if (!d_acc || d_acc->P <= 0 || !d_rate || !d_code || cov < 1) return fail(ctx, AMPLI_E_INVALID, "error_finalize: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long P = d_acc->P;
-    hipLaunchKernelGGL(error_finalize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P,
-                       C, (int)cov, d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags);
-    return check_launch(ctx, "error_finalize_kernel");
+    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags};
+    return launch_finalize(ctx, to_ptrs(d_acc), P, C, (int)cov, fo);
 }
 
 extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
@@ -1318,6 +1379,8 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long R = P + E;
     dim3 grid((unsigned)((R + 255) / 256), (unsigned)((T + PC_SAMPLES - 1) / PC_SAMPLES));
+    if (d_n_calls && (mode == AMPLI_POISSON_FULL || d_af)) // the two-kernel path resets the counters in-kernel
+        HIP_TRY(ctx, hipMemsetAsync(d_n_calls, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
     if (mode == AMPLI_POISSON_FULL)
         hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_FULL>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
                            (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
@@ -1360,7 +1423,7 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         dim3 qgrid((unsigned)tiles, (unsigned)gy);
         hipLaunchKernelGGL(poisson_stream_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P, (long long)E,
                            d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
-                           (unsigned *)d_call_mask, ctx->d_flags);
+                           (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, ctx->stream, (const PcItem *)ctx->queue,

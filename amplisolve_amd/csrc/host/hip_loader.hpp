@@ -27,6 +27,8 @@ struct HipApi {
     int (*acc_bind)(void *, int64_t, ampli_acc_table *);
     int (*error_reduce)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, int32_t, float, int32_t,
                         const ampli_acc_table *);
+    int (*error_estimate)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, float, int32_t,
+                          const ampli_acc_table *, float *, uint8_t *, float *, float *, uint8_t *, int32_t *);
     int (*error_finalize)(ampli_ctx *, const ampli_acc_table *, float, int32_t, float *, uint8_t *, float *, float *, uint8_t *,
                           int32_t *);
     int (*set_tuning)(ampli_ctx *, int32_t, int32_t);

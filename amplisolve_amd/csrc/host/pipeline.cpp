@@ -165,22 +165,22 @@ int run_error_estimation(const EeArgs &a)
         const int64_t P = co.P, R = co.R();
         int32_t *d_recs = dev.upload(co.recs, (size_t)co.S() * R * 8);
         uint32_t *d_dup = co.E ? dev.upload(co.dup_off.data(), co.dup_off.size()) : nullptr;
-        void *d_accbuf = dev.alloc<char>(dev.api->acc_bytes(P));
-        ampli_acc_table acc;
-        dev.check(dev.api->acc_bind(d_accbuf, P, &acc), "ampli_acc_bind");
         float *d_rate = dev.alloc<float>((size_t)P * 8), *d_germ = dev.alloc<float>((size_t)P * 4);
         uint8_t *d_code = dev.alloc<uint8_t>((size_t)P * 4), *d_gp = dev.alloc<uint8_t>((size_t)P * 4);
         int32_t *d_flags = dev.alloc<int32_t>(1);
         dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
-        dev.check(dev.api->error_reduce(dev.ctx, d_recs, P, co.E, d_dup, co.S(), 0, C_value, cov, &acc), "ampli_error_reduce");
+        std::cout << "Running function estimateThresholds: ";
+        // reduce + finalize fused (the whole panel is on this device)
+        dev.check(dev.api->error_estimate(dev.ctx, d_recs, P, co.E, d_dup, co.S(), C_value, cov, nullptr, d_rate, d_code, nullptr, d_germ,
+                                          d_gp, d_flags), "ampli_error_estimate");
         int32_t kflags = 0;
         dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
         if (kflags & AMPLI_FLAG_RERUN_GENERAL) { // a depth beyond the fast kernel's integer envelope: literal kernel
             dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning");
-            dev.check(dev.api->error_reduce(dev.ctx, d_recs, P, co.E, d_dup, co.S(), 0, C_value, cov, &acc), "ampli_error_reduce");
+            dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
+            dev.check(dev.api->error_estimate(dev.ctx, d_recs, P, co.E, d_dup, co.S(), C_value, cov, nullptr, d_rate, d_code, nullptr,
+                                              d_germ, d_gp, d_flags), "ampli_error_estimate");
         }
-        std::cout << "Running function estimateThresholds: ";
-        dev.check(dev.api->error_finalize(dev.ctx, &acc, C_value, cov, d_rate, d_code, nullptr, d_germ, d_gp, d_flags), "ampli_error_finalize");
         std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
         std::vector<uint8_t> code((size_t)P * 4), gp((size_t)P * 4);
         int32_t flags = 0;

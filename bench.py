@@ -199,16 +199,20 @@ def main():
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
 
     def reduce_part(i, timed, slot):
+        nonlocal fin
         if timed:
             ctx.record(ev[i][0])
-        ctx.error_reduce(normals, P, 0.002, 100, first_sample=rank * S, acc=accs[slot])
+        if world == 1:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
+            fin = ctx.error_estimate(normals, P, 0.002, 100, out=fin)
+        else:
+            ctx.error_reduce(normals, P, 0.002, 100, first_sample=rank * S, acc=accs[slot])
         if timed:
             ctx.record(ev[i][1])
 
     def call_part(i, timed, slot):
         nonlocal fin
-        fin = ctx.error_finalize(accs[slot], 0.002, 100, out=fin)
-        n_calls.zero_()
+        if world > 1:
+            fin = ctx.error_finalize(accs[slot], 0.002, 100, out=fin)
         if timed:
             ctx.record(ev[i][2])
         ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
@@ -297,7 +301,9 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         evals = world * (P * S + P * T) * args.steps
         acc_bytes = ctx.lib.ampli_acc_bytes(P)
-        red_bytes = 32 * P * S + acc_bytes                 # algorithmic bytes of error_reduce per launch
+        # algorithmic bytes of error_reduce per launch: the records + what it writes (the accumulator table,
+        # or at N = 1 the finalised error table: rate 32 B + thr 32 B + code 4 B + germ 16+4 B per position)
+        red_bytes = 32 * P * S + (acc_bytes if world > 1 else 88 * P)
         call_bytes = 32 * P * T + 33 * P + P * T           # poisson_call: records + thresholds/ref + mask
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = "error_reduce_kernel<true>", t_red, red_bytes

@@ -135,6 +135,17 @@ int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t
                        int32_t coverage_cutoff, const ampli_acc_table *d_acc);
 
 /*
+ * error_estimate -- error_reduce + error_finalize in one call for a panel that lives on ONE device (the
+ * single-GPU command line): the merged per-position state is finalised in the reduce kernel's epilogue, so the
+ * accumulator table never travels through HBM (d_acc may be NULL; pass a table to get it as well).  Outputs as
+ * for ampli_error_finalize.  Falls back to reduce -> merge -> finalize internally when the sample axis has to be
+ * split across workgroups (small panels).
+ */
+int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                         int32_t S, float C, int32_t coverage_cutoff, const ampli_acc_table *d_acc, float *d_rate,
+                         uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
+
+/*
  * acc_merge -- ordered combine of nparts partial tables (parts[0] = earliest
  * samples) into d_dst (may alias parts[0]).  Sums add; the germ-max triple
  * composes as the reference's sequential state machine would.  This is the
@@ -197,8 +208,8 @@ typedef struct ampli_call {
  *   d_calls / capacity / d_n_calls: optional compact list of emitted calls, kept as AMPLI_CALL_SHARDS independent
  *     segments so that appends do not serialise on one counter: segment k = entries [k*(capacity/SHARDS), ...),
  *     its fill count is d_n_calls[k*AMPLI_CALL_COUNTER_STRIDE] (a count above capacity/SHARDS means that segment
- *     overflowed: rerun with a larger capacity).  d_n_calls points to AMPLI_CALL_COUNTER_WORDS uint64 words that the
- *     caller zeroes (ampli_memset_d).  Entries are unordered: sort by (sample, record, alt) for the reference's
+ *     overflowed: rerun with a larger capacity).  d_n_calls points to AMPLI_CALL_COUNTER_WORDS uint64 words; the
+ *     call resets them itself.  Entries are unordered: sort by (sample, record, alt) for the reference's
  *     emission order.  d_n_calls without d_calls just counts.
  *   d_q [T][R][4][2] double, optional dense scores (Q_fw,Q_bw per nucleotide; -1 = not evaluated;
  *     requires mode FULL); d_af [T][R][4][3] float optional dense {AF, AF_fw, AF_bw}.

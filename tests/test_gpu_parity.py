@@ -363,3 +363,22 @@ def test_deep_coverage_stress_config5_shape(ctx):
     exp = orc.poisson_call(trecs[:, sl].cpu().numpy(), 700, fin.thr[:, :, sl].cpu().numpy(), refc[sl].cpu().numpy(), 100, dense=False)
     assert np.array_equal(pre["call_mask"][:, sl].cpu().numpy(), exp["call_mask"])
     assert ctx.n_calls_total(pre) > 0
+
+
+@pytest.mark.parametrize("P,S,splits", [(64, 4, 1), (1000, 33, 3), (5000, 64, 0), (33, 200, 0)])
+def test_error_estimate_fused_equals_two_step(ctx, P, S, splits):
+    """ampli_error_estimate (finalize fused into the reduce epilogue, table optional) == reduce + finalize."""
+    import torch
+
+    recs = _t(synth_recs(P, S))
+    ref = orc.error_finalize(orc.error_reduce(recs.cpu().numpy(), P, 0.002, 100))
+    ctx.set_tuning(splits)
+    fused = ctx.error_estimate(recs, P, 0.002, 100)                      # no table at all
+    acc = ctx.new_acc(P)
+    fused2 = ctx.error_estimate(recs, P, 0.002, 100, acc=acc)            # table as a by-product
+    two = ctx.error_finalize(ctx.error_reduce(recs, P, 0.002, 100), 0.002, 100)
+    ctx.set_tuning(0)
+    for f in (fused, fused2, two):
+        assert_final_equal(f, ref)
+    ref_acc = orc.error_reduce(recs.cpu().numpy(), P, 0.002, 100)
+    assert_acc_equal(acc, ref_acc)
