@@ -214,6 +214,21 @@ extern "C" int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear)
     return AMPLI_OK;
 }
 
+// streaming 16-byte load of record data (read once per launch): optionally non-temporal
+#ifndef AMPLI_NT_LOADS
+#define AMPLI_NT_LOADS 0
+#endif
+__device__ __forceinline__ int4 ld_stream(const int4 *p)
+{
+#if AMPLI_NT_LOADS
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = __builtin_nontemporal_load((const v4i *)p);
+    return make_int4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // accumulator table layout
 // ---------------------------------------------------------------------------
@@ -676,14 +691,14 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     // (chunk_len) is wave-uniform and rows past a group's chunk are loaded clamped and not visited
     const size_t row_stride = (size_t)R * 2;
     const int4 *q = recs + ((size_t)min(s0, S - 1) * R + p) * 2;
-    int4 n0 = q[0], n1 = q[1];
+    int4 n0 = ld_stream(q), n1 = ld_stream(q + 1);
     for (int i = 0; i < chunk_len; ++i) {
         const int s = s0 + i;
         const int4 c0 = n0, c1 = n1;
         if (i + 1 < chunk_len) { // prefetch while this row is consumed
             if (s + 1 < S) q += row_stride;
-            n0 = q[0];
-            n1 = q[1];
+            n0 = ld_stream(q);
+            n1 = ld_stream(q + 1);
         }
         if (s < s1) {
             if (FAST) visit_fast(f, c0, c1, first_sample + s, C, cov);
@@ -990,13 +1005,13 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
 
     const size_t row_stride = (size_t)R * 2;
     const int4 *row = recs + ((size_t)t0 * R + r) * 2;
-    int4 n0 = row[0], n1 = row[1];
+    int4 n0 = ld_stream(row), n1 = ld_stream(row + 1);
     for (int dt = 0; dt < nt_rows; ++dt) {
         const int4 r0v = n0, r1v = n1;
         if (dt + 1 < nt_rows) { // prefetch the next sample row
             row += row_stride;
-            n0 = row[0];
-            n1 = row[1];
+            n0 = ld_stream(row);
+            n1 = ld_stream(row + 1);
         }
         const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
         const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
