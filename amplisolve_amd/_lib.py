@@ -10,7 +10,7 @@ import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.environ.get("AMPLISOLVE_HIP_LIB") or os.path.join(PKG, "lib", "libamplisolve_hip.so")
-HOST_LIB_PATH = os.path.join(PKG, "lib", "libamplisolve_host.so")
+HOST_LIB_PATH = os.environ.get("AMPLISOLVE_HOST_LIB") or os.path.join(PKG, "lib", "libamplisolve_host.so")
 
 vp, i32, i64, u64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 
