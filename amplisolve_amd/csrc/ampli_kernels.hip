@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
             te[st][nt] = ampli_effective_err(thr[(st * 4 + nt) * P + p]); // VC:887-890
         }
     }
-    const unsigned shard = blockIdx.x % AMPLI_CALL_SHARDS;
+    const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS; // workgroups dealt round-robin
 
     const size_t row_stride = (size_t)R * 2;
     const int4 *row = recs + ((size_t)t0 * R + r) * 2;
@@ -1405,9 +1405,21 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
                            (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
                            (long long)capacity, d_n_calls, d_q, d_af);
     else {
-        // queue workspace: T*R/4 items (the synthetic and Toy_data panels queue ~0.2 % of the records), grown on demand
+        // rows per workgroup: one balanced wave of workgroups when the panel is small enough, else whole columns
+        const long long tiles = (R + 255) / 256;
+        const long long resident = (long long)ctx->n_cu * 8; // 256-thread workgroups at <= 64 VGPRs
+        long long gy = resident / tiles;
+        if (gy < 1) gy = 1;
+        if (gy > T) gy = T;
+        int rows = (int)((T + gy - 1) / gy);
+        if (rows < 4 && T >= 4) rows = 4; // keep the per-position constants amortised
+        gy = (T + rows - 1) / rows;
+        // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),
+        // or what ampli_set_queue_items asked for plus one workgroup's worth of slack per shard (workgroups are dealt
+        // to the shards round-robin, so a shard holds at most ceil(blocks/SHARDS) workgroups' items)
         size_t want = (size_t)std::max<long long>(1 << 16, (long long)T * R / 4);
-        if (ctx->queue_min_items > want) want = ctx->queue_min_items;
+        const size_t slack = (size_t)AMPLI_CALL_SHARDS * 256 * 3 * (size_t)rows;
+        if (ctx->queue_min_items) want = std::max(want, ctx->queue_min_items + slack);
         want = (want + AMPLI_CALL_SHARDS - 1) / AMPLI_CALL_SHARDS * AMPLI_CALL_SHARDS;
         if (ctx->queue_items < want) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1426,15 +1438,6 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         unsigned long long *qn = ctx->queue_n + (size_t)(ctx->queue_parity & 1) * AMPLI_CALL_COUNTER_WORDS;
         unsigned long long *qn_next = ctx->queue_n + (size_t)((ctx->queue_parity + 1) & 1) * AMPLI_CALL_COUNTER_WORDS;
         ctx->queue_parity ^= 1;
-        // rows per workgroup: one balanced wave of workgroups when the panel is small enough, else whole columns
-        const long long tiles = (R + 255) / 256;
-        const long long resident = (long long)ctx->n_cu * 8; // 256-thread workgroups at <= 64 VGPRs
-        long long gy = resident / tiles;
-        if (gy < 1) gy = 1;
-        if (gy > T) gy = T;
-        int rows = (int)((T + gy - 1) / gy);
-        if (rows < 4 && T >= 4) rows = 4; // keep the per-position constants amortised
-        gy = (T + rows - 1) / rows;
         dim3 qgrid((unsigned)tiles, (unsigned)gy);
         hipLaunchKernelGGL(poisson_stream_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P, (long long)E,
                            d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,

@@ -33,6 +33,7 @@ struct HipApi {
                           int32_t *);
     int (*set_tuning)(ampli_ctx *, int32_t, int32_t);
     int (*ctx_flags)(ampli_ctx *, int32_t *, int32_t);
+    int (*set_queue_items)(ampli_ctx *, int64_t);
     int (*poisson_call)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, const float *,
                         const uint8_t *, int32_t, int32_t, uint8_t *, ampli_call *, int64_t, unsigned long long *, double *,
                         float *);

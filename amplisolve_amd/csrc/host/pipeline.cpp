@@ -279,13 +279,19 @@ int run_variant_calling(const VcArgs &a)
             uint8_t *d_mask = dev.alloc<uint8_t>((size_t)T * R);
             unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
             int64_t cap = std::max<int64_t>(1 << 16, (int64_t)T * R / 16);
-            for (int attempt = 0; attempt < 3; ++attempt) {
+            for (int attempt = 0; attempt < 4; ++attempt) {
                 cap -= cap % AMPLI_CALL_SHARDS;
                 const int64_t per = cap / AMPLI_CALL_SHARDS;
                 ampli_call *d_calls = dev.alloc<ampli_call>((size_t)cap);
                 dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
                 dev.check(dev.api->poisson_call(dev.ctx, d_recs, P, co.E, d_ext, T, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask,
                                                 d_calls, cap, d_n, nullptr, nullptr), "ampli_poisson_call");
+                int32_t kflags = 0;
+                dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+                if (kflags & AMPLI_FLAG_QUEUE_OVERFLOW) { // more survivors than the default queue holds: size it for the worst case
+                    dev.check(dev.api->set_queue_items(dev.ctx, (int64_t)T * R * 3), "ampli_set_queue_items");
+                    continue;
+                }
                 std::vector<unsigned long long> n(AMPLI_CALL_COUNTER_WORDS);
                 dev.download(n.data(), d_n, n.size());
                 dev.sync();

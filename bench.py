@@ -100,7 +100,7 @@ def cpu_baseline(cfg):
 
     out = {}
     # --- port (oracle) on both halves -----------------------------------------------------------
-    P, S, T = 20_000, 64, 24
+    P, S, T = 50_000, 128, 48
     normals = synth_recs(P, S, seed=SEED, depth=cfg["depth"])
     tumours = synth_recs(P, T, seed=SEED, depth=cfg["depth"], tumour=True)
     ref = synth_ref(P, seed=SEED)
@@ -117,7 +117,7 @@ def cpu_baseline(cfg):
     # --- the reference's own code for the error-estimation half --------------------------------
     drv = orc.REF_EE_DRIVER
     if os.path.exists(drv):
-        Pr, Sr = 10_000, 24
+        Pr, Sr = 20_000, 64
         rows, pos = synthetic_panel(Pr)
         recs = synth_recs(Pr, Sr, seed=SEED, depth=cfg["depth"])
         refb = synth_ref(Pr, seed=SEED)

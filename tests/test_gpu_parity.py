@@ -382,3 +382,40 @@ def test_error_estimate_fused_equals_two_step(ctx, P, S, splits):
         assert_final_equal(f, ref)
     ref_acc = orc.error_reduce(recs.cpu().numpy(), P, 0.002, 100)
     assert_acc_equal(acc, ref_acc)
+
+
+def test_prefilter_queue_overflow_is_flagged_and_recoverable(ctx):
+    """Every record carries strong variants on both strands: far more survivors than the default queue (T*R/4 items)
+    holds.  The kernel must raise AMPLI_FLAG_QUEUE_OVERFLOW rather than silently drop work; with a larger queue the
+    result equals the oracle and the full-mode kernel."""
+    import torch
+
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    P, T = 70_000, 4
+    rng = np.random.default_rng(17)
+    trecs = np.zeros((T, P, 8), np.int32)
+    trecs[:, :, 0] = 900; trecs[:, :, 4] = 850                      # reference A
+    trecs[:, :, 1] = rng.integers(20, 60, (T, P)); trecs[:, :, 5] = rng.integers(20, 60, (T, P))
+    trecs[:, :, 2] = rng.integers(15, 50, (T, P)); trecs[:, :, 6] = rng.integers(15, 50, (T, P))
+    trecs[:, :, 3] = rng.integers(10, 40, (T, P)); trecs[:, :, 7] = rng.integers(10, 40, (T, P))
+    thr = np.full((2, 4, P), 0.002, np.float32)
+    ref_code = np.zeros(P, np.uint8)
+    d_t, d_thr, d_ref = _t(trecs), _t(thr), _t(ref_code)
+    from amplisolve_amd import Context
+
+    ctx = Context(0)  # a fresh context: its queue has the default size, not what earlier tests grew it to
+    ctx.poisson_call(d_t, P, d_thr, d_ref, 100, mode=POISSON_PREFILTER)
+    assert ctx.flags() & 4
+    ctx.set_queue_items(3 * T * P)
+    pre = ctx.poisson_call(d_t, P, d_thr, d_ref, 100, mode=POISSON_PREFILTER, capacity=4 * T * P)  # segments fill unevenly: leave slack
+    assert ctx.flags() == 0
+    ctx.set_queue_items(0)
+    full = ctx.poisson_call(d_t, P, d_thr, d_ref, 100, mode=POISSON_FULL)
+    assert torch.equal(pre["call_mask"], full["call_mask"])
+    exp = orc.poisson_call(trecs[:, :2000], 2000, thr[:, :, :2000], ref_code[:2000], 100, dense=False)
+    assert np.array_equal(pre["call_mask"][:, :2000].cpu().numpy(), exp["call_mask"])
+    assert ctx.n_calls_total(pre) == 3 * T * P  # every alt of every record is a call
+    calls = ctx.read_calls(pre)
+    assert len(calls) == 3 * T * P and (calls["q_fw"] >= 5).all() and (calls["q_bw"] >= 5).all()
+    ctx.close()
