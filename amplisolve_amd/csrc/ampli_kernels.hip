@@ -979,7 +979,11 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     // this workgroup's slice of the call mask starts as "no call": rows [t0, t0+nt_rows) x 256 records, whole
     // words only (R is a multiple of 4 here or the tail word is shared with the next row and zeroed by both).
     {
+#if defined(AMPLI_DIAG_NOMASK)
+        for (int i = threadIdx.x; i < nt_rows * 64 && P < 0; i += 256) {
+#else
         for (int i = threadIdx.x; i < nt_rows * 64; i += 256) {
+#endif
             const int dt = i >> 6, w = i & 63;
             const long long rec = (long long)blockIdx.x * 256 + (long long)w * 4;
             if (rec < R) {
@@ -1029,7 +1033,11 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
         for (int nt = 0; nt < 4; ++nt) {
             const bool skip_fw = exact && (unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)fw[nt] <= c_fw * te[0][nt];
             const bool skip_bw = exact && (unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)bw[nt] <= c_bw * te[1][nt];
+#if defined(AMPLI_DIAG_NOPUSH)
+            if (live && nt != ref && !skip_fw && !skip_bw && fw[nt] == -12345) pushmask |= 1u << nt;
+#else
             if (live && nt != ref && !skip_fw && !skip_bw) pushmask |= 1u << nt;
+#endif
         }
         if (__any(pushmask != 0)) { // rare
 #pragma unroll
@@ -1074,13 +1082,15 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
     const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     // the shards form one flat index space: cum[k] = items in shards < k (clamped to the segment size)
     __shared__ long long cum[AMPLI_CALL_SHARDS + 1];
+    __shared__ long long cnt[AMPLI_CALL_SHARDS];
+    if (threadIdx.x < AMPLI_CALL_SHARDS) { // 32 independent loads in flight at once, not a serial chain of them
+        const long long n = (long long)queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE];
+        cnt[threadIdx.x] = n > queue_per_shard ? queue_per_shard : n;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         long long c = 0;
-        for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
-            cum[k] = c;
-            long long n = (long long)queue_n[k * AMPLI_CALL_COUNTER_STRIDE];
-            c += n > queue_per_shard ? queue_per_shard : n;
-        }
+        for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) { cum[k] = c; c += cnt[k]; }
         cum[AMPLI_CALL_SHARDS] = c;
     }
     __syncthreads();

@@ -306,7 +306,7 @@ def main():
         red_bytes = 32 * P * S + (acc_bytes if world > 1 else 88 * P)
         call_bytes = 32 * P * T + 33 * P + P * T           # poisson_call: records + thresholds/ref + mask
         if t_red >= t_call:
-            dom, dom_ms, dom_bytes = "error_reduce_kernel<true>", t_red, red_bytes
+            dom, dom_ms, dom_bytes = "error_reduce_kernel<true, 1>", t_red, red_bytes
         else:
             dom, dom_ms, dom_bytes = "poisson_stream_kernel+poisson_drain_kernel", t_call, call_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
