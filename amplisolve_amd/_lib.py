@@ -57,6 +57,9 @@ HIP_SYMBOLS = {
     "ampli_error_reduce": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, C.POINTER(AccTable)]),
     "ampli_error_estimate": (C.c_int, [vp, vp, i64, i64, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ampli_acc_merge": (C.c_int, [vp, C.POINTER(AccTable), C.POINTER(AccTable), i32]),
+    "ampli_acc_packed_len": (i64, [i64]),
+    "ampli_acc_pack": (C.c_int, [vp, C.POINTER(AccTable), vp]),
+    "ampli_acc_unpack": (C.c_int, [vp, vp, C.POINTER(AccTable)]),
     "ampli_acc_regions": (C.c_int, [i64, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "ampli_gm_merge": (C.c_int, [vp, C.POINTER(AccTable), vp, i32]),
     "ampli_error_finalize": (C.c_int, [vp, C.POINTER(AccTable), f32, i32, vp, vp, vp, vp, vp, vp]),

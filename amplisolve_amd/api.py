@@ -198,6 +198,12 @@ class Context:
         self._check(self.lib.ampli_acc_regions(P, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def acc_pack(self, acc: Acc, packed):
+        self._check(self.lib.ampli_acc_pack(self.h, C.byref(acc.struct), _ptr(packed)))
+
+    def acc_unpack(self, packed, acc: Acc):
+        self._check(self.lib.ampli_acc_unpack(self.h, _ptr(packed), C.byref(acc.struct)))
+
     def gm_merge(self, dst: Acc, regions, nparts: int):
         """regions: uint8 tensor holding nparts gathered gm regions back to back."""
         self._check(self.lib.ampli_gm_merge(self.h, C.byref(dst.struct), _ptr(regions), nparts))

@@ -789,6 +789,34 @@ __global__ __launch_bounds__(256) void acc_merge_ptr_kernel(AccPtrs dst, const A
     lane_acc_store(dst, P, p, a);
 }
 
+// ---------------------------------------------------------------------------
+// pack / unpack of the additive planes for the multi-GPU merge: ONE float64 buffer
+// [snt 8P | srd 8P | cnt 4P | nrec P] so that the shards merge with a single RCCL all-reduce (SUM).
+// srd / cnt / nrec are integers far below 2^53: exact in a double, exact under any summation order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void acc_pack_kernel(AccPtrs t, const long long P, double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 21 * P) return;
+    double v;
+    if (i < 8 * P) v = t.snt[i];
+    else if (i < 16 * P) v = (double)t.srd[i - 8 * P];
+    else if (i < 20 * P) v = (double)t.cnt[i - 16 * P];
+    else v = (double)t.nrec[i - 20 * P];
+    out[i] = v;
+}
+
+__global__ __launch_bounds__(256) void acc_unpack_kernel(AccPtrs t, const long long P, const double *__restrict__ in)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 21 * P) return;
+    const double v = in[i];
+    if (i < 8 * P) t.snt[i] = v;
+    else if (i < 16 * P) t.srd[i - 8 * P] = (long long)v;
+    else if (i < 20 * P) t.cnt[i - 16 * P] = (int)v;
+    else t.nrec[i - 20 * P] = (int)v;
+}
+
 // germ-max triples only.  regions: nparts copies of the gm region of a table (gm_n .. end of gm_rest),
 // region k at regions + k*stride; plane offsets inside a region as in the table.
 __global__ __launch_bounds__(256) void gm_merge_kernel(int *gm_n, int *gm_first, float *gm_first_af, float *gm_rest,
@@ -1348,6 +1376,28 @@ extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, con
     hipLaunchKernelGGL(acc_merge_ptr_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_dst),
                        (const AccPtrs *)ctx->ws, (int)nparts, (long long)P);
     return check_launch(ctx, "acc_merge_ptr_kernel");
+}
+
+extern "C" int64_t ampli_acc_packed_len(int64_t P) { return P > 0 ? 21 * P : 0; }
+
+extern "C" int ampli_acc_pack(ampli_ctx *ctx, const ampli_acc_table *d_acc, double *d_packed)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_acc || d_acc->P <= 0 || !d_packed) return fail(ctx, AMPLI_E_INVALID, "acc_pack: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long P = d_acc->P;
+    hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, d_packed);
+    return check_launch(ctx, "acc_pack_kernel");
+}
+
+extern "C" int ampli_acc_unpack(ampli_ctx *ctx, const double *d_packed, const ampli_acc_table *d_acc)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_acc || d_acc->P <= 0 || !d_packed) return fail(ctx, AMPLI_E_INVALID, "acc_unpack: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long P = d_acc->P;
+    hipLaunchKernelGGL(acc_unpack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, d_packed);
+    return check_launch(ctx, "acc_unpack_kernel");
 }
 
 extern "C" int ampli_acc_regions(int64_t P, size_t *sum_bytes, size_t *gm_offset, size_t *gm_bytes)

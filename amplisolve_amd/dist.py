@@ -67,10 +67,13 @@ class TableMerger:
     RCCL's own stream over xGMI while the CUs keep streaming HBM.
     """
 
-    def __init__(self, P: int, world: int, device, fold, group=None):
+    def __init__(self, P: int, world: int, device, fold, group=None, pack=None, unpack=None):
+        """pack(acc, buf) / unpack(buf, acc): Context.acc_pack / acc_unpack on the GPU (one kernel each);
+        default: torch copies (CPU tests)."""
         import torch
 
         self.P, self.world, self.group, self.fold = P, world, group, fold
+        self.pack, self.unpack = pack, unpack
         _, self.gm_off, self.gm_bytes = table_regions(P)
         self.packed = [torch.empty(21 * P, dtype=torch.float64, device=device) for _ in range(2)]
         self.gathered = [torch.empty(world * self.gm_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
@@ -79,10 +82,13 @@ class TableMerger:
         import torch.distributed as dist
 
         P, pk = self.P, self.packed[slot]
-        pk[0:8 * P].copy_(acc.snt.view(-1))
-        pk[8 * P:16 * P].copy_(acc.srd.view(-1))
-        pk[16 * P:20 * P].copy_(acc.cnt.view(-1))
-        pk[20 * P:21 * P].copy_(acc.nrec)
+        if self.pack is not None:
+            self.pack(acc, pk)
+        else:
+            pk[0:8 * P].copy_(acc.snt.view(-1))
+            pk[8 * P:16 * P].copy_(acc.srd.view(-1))
+            pk[16 * P:20 * P].copy_(acc.cnt.view(-1))
+            pk[20 * P:21 * P].copy_(acc.nrec)
         w_g = dist.all_gather_into_tensor(self.gathered[slot], acc.buf[self.gm_off: self.gm_off + self.gm_bytes],
                                           group=self.group, async_op=True)
         w_r = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -92,10 +98,13 @@ class TableMerger:
         P, pk = self.P, self.packed[slot]
         w_r, w_g = handle
         w_r.wait()
-        acc.snt.view(-1).copy_(pk[0:8 * P])
-        acc.srd.view(-1).copy_(pk[8 * P:16 * P])
-        acc.cnt.view(-1).copy_(pk[16 * P:20 * P])
-        acc.nrec.copy_(pk[20 * P:21 * P])
+        if self.unpack is not None:
+            self.unpack(pk, acc)
+        else:
+            acc.snt.view(-1).copy_(pk[0:8 * P])
+            acc.srd.view(-1).copy_(pk[8 * P:16 * P])
+            acc.cnt.view(-1).copy_(pk[16 * P:20 * P])
+            acc.nrec.copy_(pk[20 * P:21 * P])
         w_g.wait()
         self.fold(acc, self.gathered[slot], self.world)
         return acc

@@ -194,7 +194,7 @@ def main():
 
     calls_buf = torch.empty((cap * ctypes.sizeof(Call),), dtype=torch.uint8, device=ctx.device)
     n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=ctx.device)
-    merger = TableMerger(P, world, ctx.device, ctx.gm_merge) if world > 1 else None
+    merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack) if world > 1 else None
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
 

@@ -159,6 +159,12 @@ int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_ac
  * holds gm_n | gm_first | gm_first_af | gm_rest (all-gather it BEFORE gm_n is reduced). */
 int ampli_acc_regions(int64_t P, size_t *sum_bytes, size_t *gm_offset, size_t *gm_bytes);
 
+/* The additive planes as ONE float64 buffer [snt 8P | srd 8P | cnt 4P | nrec P] (ampli_acc_packed_len(P) = 21*P
+ * doubles) so that the shards merge with a single all-reduce (SUM); the integers are exact in a double. */
+int64_t ampli_acc_packed_len(int64_t P);
+int ampli_acc_pack(ampli_ctx *ctx, const ampli_acc_table *d_acc, double *d_packed);
+int ampli_acc_unpack(ampli_ctx *ctx, const double *d_packed, const ampli_acc_table *d_acc);
+
 /* gm_merge -- fold nparts gathered gm regions (region k = shard k, ascending sample order, laid out
  * back to back, gm_bytes each) into d_dst's germ-max planes.  The sequential state machine of
  * EE:1251-1271 composes over shards exactly as ampli_acc_merge does. */

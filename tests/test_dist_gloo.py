@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from amplisolve_amd.api import Acc
-from amplisolve_amd.dist import merge_error_table, shard_range, table_regions
+from amplisolve_amd.dist import TableMerger, merge_error_table, shard_range, table_regions
 from oracle import pyoracle as orc
 from tests.helpers import synth_recs
 
@@ -66,6 +66,24 @@ def worker(rank, world, port, q):
         ok &= bool(np.array_equal(acc.gm_first.numpy()[m1], full["gm_first"][m1]))
         ok &= bool(np.array_equal(acc.gm_first_af.numpy()[m1].view(np.int32), full["gm_first_af"][m1].view(np.int32)))
         ok &= bool(np.array_equal(acc.gm_rest.numpy()[m2].view(np.int32), full["gm_rest"][m2].view(np.int32)))
+        # the pipelined, double-buffered form bench.py uses at N > 1: two batches in flight
+        merger = TableMerger(P, world, "cpu", host_fold)
+        batches = []
+        for b in range(2):
+            rb = synth_recs(P, S, seed=1234 + b)
+            pb = orc.error_reduce(rb[lo:hi], P, 0.002, 100, first_sample=lo)
+            ab = Acc(None, P, device="cpu")
+            ab.buf.zero_()
+            for name in ("snt", "srd", "cnt", "nrec", "gm_n", "gm_first", "gm_first_af", "gm_rest"):
+                getattr(ab, name).copy_(torch.from_numpy(pb[name]))
+            batches.append((rb, ab, merger.start(ab, b)))
+        for b, (rb, ab, h) in enumerate(batches):
+            merger.finish(ab, b, h)
+            fb = orc.error_reduce(rb, P, 0.002, 100)
+            for name in ("snt", "srd", "cnt", "nrec", "gm_n"):
+                ok &= bool(np.array_equal(getattr(ab, name).numpy(), fb[name]))
+            mb = fb["gm_n"] > 1
+            ok &= bool(np.array_equal(ab.gm_rest.numpy()[mb].view(np.int32), fb["gm_rest"][mb].view(np.int32)))
         fin_a = orc.error_finalize({k: getattr(acc, k).numpy() for k in ("snt", "srd", "cnt", "nrec", "gm_n", "gm_rest")})
         fin_b = orc.error_finalize(full)
         ok &= all(np.array_equal(fin_a[k], fin_b[k], equal_nan=True) for k in fin_a)
