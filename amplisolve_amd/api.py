@@ -119,6 +119,13 @@ class Context:
     def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
         self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general) | (groups << 4)))
 
+    def set_async_drain(self, on: bool):
+        """poisson_call's drain kernel on a side stream; results complete after wait_calls() / sync()."""
+        self._check(self.lib.ampli_set_async_drain(self.h, int(on)))
+
+    def wait_calls(self):
+        self._check(self.lib.ampli_wait_calls(self.h))
+
     def set_queue_items(self, items: int):
         self._check(self.lib.ampli_set_queue_items(self.h, items))
 

@@ -38,6 +38,11 @@ struct ampli_ctx {
     size_t queue_min_items = 0; // ampli_set_queue_items
     unsigned long long *queue_n = nullptr; // two counter arrays, used alternately
     unsigned queue_parity = 0;
+    // optional: the drain kernel of poisson_call on a side stream (ampli_set_async_drain)
+    int async_drain = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_stream_done = nullptr, ev_drain_done = nullptr;
+    bool drain_pending = false;
     int n_cu = 256;
 };
 
@@ -115,6 +120,9 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->queue_n) (void)hipFree(ctx->queue_n);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->ev_stream_done) (void)hipEventDestroy(ctx->ev_stream_done);
+    if (ctx->ev_drain_done) (void)hipEventDestroy(ctx->ev_drain_done);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -122,9 +130,40 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
 extern "C" const char *ampli_last_error(ampli_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 extern "C" void *ampli_stream(ampli_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+// main stream waits for the drain kernel still running on the side stream (no host block)
+static int join_drain(ampli_ctx *ctx)
+{
+    if (ctx->drain_pending) {
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_drain_done, 0));
+        ctx->drain_pending = false;
+    }
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_set_async_drain(ampli_ctx *ctx, int32_t on)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (on && !ctx->side) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_stream_done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_drain_done, hipEventDisableTiming));
+    }
+    if (!on) { int rc = join_drain(ctx); if (rc) return rc; }
+    ctx->async_drain = on ? 1 : 0;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_wait_calls(ampli_ctx *ctx)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    return join_drain(ctx);
+}
+
 extern "C" int ampli_sync(ampli_ctx *ctx)
 {
     if (!ctx) return AMPLI_E_INVALID;
+    { int rc = join_drain(ctx); if (rc) return rc; }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return AMPLI_OK;
 }
@@ -158,6 +197,7 @@ extern "C" int ampli_copy_h2d(ampli_ctx *ctx, void *d_dst, const void *src, size
 extern "C" int ampli_copy_d2h(ampli_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 {
     if (!ctx) return AMPLI_E_INVALID;
+    { int rc = join_drain(ctx); if (rc) return rc; }
     HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return AMPLI_OK;
 }
@@ -208,6 +248,7 @@ extern "C" int ampli_set_queue_items(ampli_ctx *ctx, int64_t items)
 extern "C" int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear)
 {
     if (!ctx || !out) return AMPLI_E_INVALID;
+    { int rc = join_drain(ctx); if (rc) return rc; }
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (clear) HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(int), ctx->stream));
@@ -1452,6 +1493,7 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
     if (d_n_calls && !d_calls) capacity = 0;
     if (((uintptr_t)d_trecs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rcj = join_drain(ctx); if (rcj) return rcj; } // the queue, its counters and the call list are about to be reused
     const long long R = P + E;
     dim3 grid((unsigned)((R + 255) / 256), (unsigned)((T + PC_SAMPLES - 1) / PC_SAMPLES));
     if (d_n_calls && (mode == AMPLI_POISSON_FULL || d_af)) // the two-kernel path resets the counters in-kernel
@@ -1506,9 +1548,19 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
                            (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;
-        hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, ctx->stream, (const PcItem *)ctx->queue,
+        hipStream_t dstream = ctx->stream;
+        if (ctx->async_drain) { // the drain is one scorer-chain latency long: let it run beside whatever the caller enqueues next
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_stream_done, ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_stream_done, 0));
+            dstream = ctx->side;
+        }
+        hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, dstream, (const PcItem *)ctx->queue,
                            per, qn, (const int4 *)d_trecs, (long long)P, (long long)E, d_ext_pos, d_thr,
                            (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
+        if (ctx->async_drain) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_drain_done, ctx->side));
+            ctx->drain_pending = true;
+        }
         return check_launch(ctx, "poisson_drain_kernel");
     }
     return check_launch(ctx, "poisson_call_kernel");

@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splits", type=int, default=0, help="error_reduce sample splits (0 = auto)")
     ap.add_argument("--groups", type=int, default=0, help="error_reduce lane groups per wave (0 = auto, 1, 2, 4)")
+    ap.add_argument("--async-drain", action="store_true", help="poisson_call's drain kernel on a side stream (measured: no gain on config 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
     return ap.parse_args()
@@ -198,12 +199,18 @@ def main():
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
 
+    # two error tables, used alternately: with the asynchronous drain the survivors of batch i are still being scored
+    # (reading batch i's thresholds) while batch i+1's table is being written
+    fins = [None, None]
+    if args.async_drain:
+        ctx.set_async_drain(True)
+
     def reduce_part(i, timed, slot):
         nonlocal fin
         if timed:
             ctx.record(ev[i][0])
         if world == 1:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
-            fin = ctx.error_estimate(normals, P, 0.002, 100, out=fin)
+            fins[i & 1] = fin = ctx.error_estimate(normals, P, 0.002, 100, out=fins[i & 1])
         else:
             ctx.error_reduce(normals, P, 0.002, 100, first_sample=rank * S, acc=accs[slot])
         if timed:
@@ -212,7 +219,7 @@ def main():
     def call_part(i, timed, slot):
         nonlocal fin
         if world > 1:
-            fin = ctx.error_finalize(accs[slot], 0.002, 100, out=fin)
+            fins[i & 1] = fin = ctx.error_finalize(accs[slot], 0.002, 100, out=fins[i & 1])
         if timed:
             ctx.record(ev[i][2])
         ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
@@ -283,8 +290,17 @@ def main():
         elapsed = float(te.item())
 
     t_red = sum(ctx.elapsed_ms(e[0], e[1]) for e in ev) / args.steps
-    t_call = sum(ctx.elapsed_ms(e[2], e[3]) for e in ev) / args.steps
+    t_call_main = sum(ctx.elapsed_ms(e[2], e[3]) for e in ev) / args.steps  # main-stream part (all of it unless --async-drain)
+    ctx.wait_calls()
     n_found = int(n_calls[::CALL_COUNTER_STRIDE].sum().item())
+    # the whole poisson_call (stream + drain kernels back to back), outside the timed region
+    ctx.set_async_drain(False)
+    e0, e1 = ctx.event(), ctx.event()
+    ctx.record(e0)
+    for _ in range(5):
+        ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
+    ctx.record(e1)
+    t_call = ctx.elapsed_ms(e0, e1) / 5
     # validation mode, outside the timed region: all six scores of every record, as the reference evaluates them
     e0, e1 = ctx.event(), ctx.event()
     n_calls.zero_()
@@ -344,6 +360,7 @@ def main():
                          "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)" if traffic else None},
             "kernels": {"error_reduce_ms": t_red, "error_reduce_GBs": red_bytes / (t_red * 1e-3) / 1e9,
                         "poisson_call_ms": t_call, "poisson_call_GBs": call_bytes / (t_call * 1e-3) / 1e9,
+                        "poisson_call_main_stream_ms": t_call_main, "drain": "side stream, overlapped with the next batch" if args.async_drain else "main stream",
                         "poisson_call_full_mode_ms": t_call_full,
                         "R_EE_positions_per_s": P / (t_red * 1e-3), "R_VC_evals_per_s": P * T / (t_call * 1e-3)},
             "calls_per_step": n_found,

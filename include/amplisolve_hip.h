@@ -226,6 +226,15 @@ int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_
                        uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
                        unsigned long long *d_n_calls, double *d_q, float *d_af);
 
+/* Asynchronous drain (opt-in).  In prefilter mode poisson_call is two kernels; the second (the dense drain of the
+ * queued survivors) is one fp64 scorer chain long and independent of what the caller enqueues next.  With
+ * ampli_set_async_drain(ctx, 1) it runs on a side stream of the context: the call mask, the call list and
+ * d_n_calls of a poisson_call are then complete only after ampli_wait_calls (the context's stream waits, the host
+ * does not block), ampli_sync, ampli_copy_d2h, ampli_ctx_flags or the next ampli_poisson_call; d_thr, d_trecs and
+ * the outputs must stay untouched until then. */
+int ampli_set_async_drain(ampli_ctx *ctx, int32_t on);
+int ampli_wait_calls(ampli_ctx *ctx);
+
 /* scalar scorer on the device for known-answer tests: q[i] = score(k[i], rd[i], err[i]),
  * p[i] = 1 - kf_gammaq(k, rd*err) (VC:3834-3884).  Either output may be NULL. */
 int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err,

@@ -419,3 +419,33 @@ def test_prefilter_queue_overflow_is_flagged_and_recoverable(ctx):
     calls = ctx.read_calls(pre)
     assert len(calls) == 3 * T * P and (calls["q_fw"] >= 5).all() and (calls["q_bw"] >= 5).all()
     ctx.close()
+
+
+def test_async_drain_equals_sync(ctx):
+    """The drain kernel on a side stream (opt-in) with other work enqueued behind it gives the same mask and calls."""
+    import torch
+
+    from amplisolve_amd.api import POISSON_PREFILTER
+
+    P, S, T = 30_000, 32, 12
+    normals = ctx.synth_fill(P, S)
+    tum = ctx.synth_fill(P, T, tumour=True)
+    refc = ctx.synth_ref(P)
+    fin = ctx.error_estimate(normals, P)
+    sync = ctx.poisson_call(tum, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 18)
+    sync_calls = ctx.read_calls(sync)
+    ctx.set_async_drain(True)
+    try:
+        for _ in range(3):
+            res = ctx.poisson_call(tum, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 18)
+            other = ctx.error_estimate(normals, P)      # unrelated work right behind it, into other buffers
+        ctx.wait_calls()
+        assert torch.equal(res["call_mask"], sync["call_mask"])
+        calls = ctx.read_calls(res)
+        assert len(calls) == len(sync_calls) > 0
+        for f in ("sample", "record", "alt", "q_fw", "q_bw", "af"):
+            assert np.array_equal(calls[f], sync_calls[f])
+        assert torch.equal(other.thr, fin.thr)
+    finally:
+        ctx.set_async_drain(False)
+    assert ctx.flags() == 0
