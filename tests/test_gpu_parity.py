@@ -449,3 +449,34 @@ def test_async_drain_equals_sync(ctx):
     finally:
         ctx.set_async_drain(False)
     assert ctx.flags() == 0
+
+
+@pytest.mark.parametrize("shards", [1, 2, 4, 8])
+def test_shard_count_invariance(ctx, shards):
+    """1 / 2 / 4 / 8 emulated ranks on one device (contiguous sample shards, packed SUM + ordered gm fold, exactly the
+    collectives' arithmetic) give the single-pass table and therefore the same error table, bit for bit."""
+    import torch
+
+    from amplisolve_amd.dist import shard_range
+
+    P, S = 3000, 67
+    recs = synth_recs(P, S)
+    full = orc.error_reduce(recs, P)
+    d_recs = _t(recs)
+    parts = []
+    for r in range(shards):
+        lo, hi = shard_range(S, r, shards)
+        parts.append(ctx.error_reduce(d_recs[lo:hi].contiguous(), P, first_sample=lo))
+    # what the all-reduce computes: the sum of the packed buffers; what the all-gather delivers: the gm regions in rank order
+    packed = [torch.empty(21 * P, dtype=torch.float64, device="cuda") for _ in parts]
+    for a, pk in zip(parts, packed):
+        ctx.acc_pack(a, pk)
+    total = torch.stack(packed).sum(0)
+    _, gm_off, gm_bytes = ctx.regions(P)
+    gathered = torch.cat([a.buf[gm_off: gm_off + gm_bytes] for a in parts])
+    dst = ctx.new_acc(P)
+    dst.buf.zero_()
+    ctx.acc_unpack(total, dst)
+    ctx.gm_merge(dst, gathered, shards)
+    assert_acc_equal(dst, full)
+    assert_final_equal(ctx.error_finalize(dst), orc.error_finalize(full))
