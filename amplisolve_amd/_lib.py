@@ -56,6 +56,8 @@ HIP_SYMBOLS = {
     "ampli_acc_bind": (C.c_int, [vp, i64, C.POINTER(AccTable)]),
     "ampli_error_reduce": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, C.POINTER(AccTable)]),
     "ampli_error_estimate": (C.c_int, [vp, vp, i64, i64, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "ampli_error_reduce_packed": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, C.POINTER(AccTable), vp]),
+    "ampli_error_finalize_merged": (C.c_int, [vp, i64, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
     "ampli_acc_merge": (C.c_int, [vp, C.POINTER(AccTable), C.POINTER(AccTable), i32]),
     "ampli_acc_packed_len": (i64, [i64]),
     "ampli_acc_pack": (C.c_int, [vp, C.POINTER(AccTable), vp]),

@@ -192,6 +192,22 @@ class Context:
                                                   _ptr(out.thr), _ptr(out.germ_val), _ptr(out.germ_present), _ptr(out.flags)))
         return out
 
+    def error_reduce_packed(self, recs, P: int, acc: Acc, packed, C_value: float = 0.002, cov: int = 100, E: int = 0,
+                            dup_off=None, first_sample: int = 0):
+        """Shard reduction for the multi-GPU merge: additive planes -> packed (float64 [21*P]), gm planes -> acc."""
+        S = recs.shape[0]
+        self._check(self.lib.ampli_error_reduce_packed(self.h, _ptr(recs), P, E, _ptr(dup_off), S, first_sample, C_value, cov,
+                                                       C.byref(acc.struct), _ptr(packed)))
+
+    def error_finalize_merged(self, P: int, packed, gm_regions, nparts: int, C_value: float = 0.002, cov: int = 100,
+                              out: ErrorTable | None = None) -> ErrorTable:
+        if out is None:
+            out = self._new_error_table(P)
+        self._check(self.lib.ampli_error_finalize_merged(self.h, P, _ptr(packed), _ptr(gm_regions), nparts, C_value, cov,
+                                                         _ptr(out.rate), _ptr(out.code), _ptr(out.thr), _ptr(out.germ_val),
+                                                         _ptr(out.germ_present), _ptr(out.flags)))
+        return out
+
     def acc_merge(self, parts: list[Acc], dst: Acc | None = None) -> Acc:
         if dst is None:
             dst = self.new_acc(parts[0].P)

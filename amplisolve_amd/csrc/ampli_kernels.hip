@@ -474,7 +474,33 @@ __device__ __forceinline__ void lane_acc_load(const AccPtrs &t, long long P, lon
 // ---------------------------------------------------------------------------
 struct FinOut {
     float *rate; unsigned char *code; float *thr; float *germ_val; unsigned char *germ_present; int *flags;
+    double *packed; // optional: the additive planes as [snt 8P | srd 8P | cnt 4P | nrec P] doubles (multi-GPU merge)
 };
+
+__device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, const long long P, const long long p, const LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        pk[(0 * 4 + nt) * P + p] = a.snt[0][nt];
+        pk[(1 * 4 + nt) * P + p] = a.snt[1][nt];
+        pk[8 * P + (0 * 4 + nt) * P + p] = (double)a.srd[0][nt];
+        pk[8 * P + (1 * 4 + nt) * P + p] = (double)a.srd[1][nt];
+        pk[16 * P + nt * P + p] = (double)a.cnt[nt];
+    }
+    pk[20 * P + p] = (double)a.nrec;
+}
+
+// germ-max planes only (the additive planes travel in the packed buffer)
+__device__ __forceinline__ void lane_acc_store_gm(const AccPtrs &t, const long long P, const long long p, const LaneAcc &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        t.gm_n[nt * P + p] = a.gm_n[nt];
+        t.gm_first[nt * P + p] = a.gm_first[nt];
+        t.gm_first_af[nt * P + p] = a.gm_first_af[nt];
+        t.gm_rest[nt * P + p] = a.gm_rest[nt];
+    }
+}
 
 __device__ __forceinline__ void finalize_lane(const LaneAcc &a, const long long P, const long long p, const float C,
                                               const int cov, const FinOut &o)
@@ -784,7 +810,12 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
         if (valid && group == 0) {
             if (out_base) {
                 const AccPtrs t = acc_at(out_base + (size_t)blockIdx.y * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7);
-                lane_acc_store(t, P, p_raw, a);
+                if (fin.packed) { // multi-GPU shard: sums straight into the all-reduce buffer, table keeps the gm planes
+                    lane_acc_store_packed(fin.packed, P, p_raw, a);
+                    lane_acc_store_gm(t, P, p_raw, a);
+                } else {
+                    lane_acc_store(t, P, p_raw, a);
+                }
             }
             // fused epilogue (single split only): the merged state is in registers, finalize it here and spare the
             // table round trip through HBM plus a launch
@@ -903,6 +934,41 @@ __global__ __launch_bounds__(256) void error_finalize_kernel(AccPtrs t, const lo
 // workgroup so the position's 8 thresholds + reference code are loaded once
 // and reused from registers.
 // ---------------------------------------------------------------------------
+// finalize straight from the merged pieces of a multi-GPU reduction: the all-reduced packed sums and the gathered
+// germ-max regions (folded here in rank order); no accumulator table is read or written.
+__global__ __launch_bounds__(256) void error_finalize_merged_kernel(const double *__restrict__ pk, const char *__restrict__ regions,
+                                                                    const size_t stride, const size_t ofa, const size_t orr,
+                                                                    const int nparts, const long long P, const float C,
+                                                                    const int cov, FinOut o)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    LaneAcc a;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        a.snt[0][nt] = pk[(0 * 4 + nt) * P + p];
+        a.snt[1][nt] = pk[(1 * 4 + nt) * P + p];
+        a.srd[0][nt] = (long long)pk[8 * P + (0 * 4 + nt) * P + p];
+        a.srd[1][nt] = (long long)pk[8 * P + (1 * 4 + nt) * P + p];
+        a.cnt[nt] = (int)pk[16 * P + nt * P + p];
+        int n = 0;
+        float rest = -INFINITY;
+        for (int k = 0; k < nparts; ++k) { // ordered fold of the shards' germ-max triples (as gm_merge_kernel)
+            const char *b = regions + (size_t)k * stride;
+            const long long i = nt * P + p;
+            const int rn = ((const int *)b)[i];
+            if (rn == 0) continue;
+            const float fa = ((const float *)(b + ofa))[i], rr = ((const float *)(b + orr))[i];
+            if (n == 0) rest = rr;
+            else { if (rest <= fa) rest = fa; if (rest <= rr) rest = rr; }
+            n += rn;
+        }
+        a.gm_n[nt] = n; a.gm_rest[nt] = rest; a.gm_first[nt] = 0; a.gm_first_af[nt] = 0.0f;
+    }
+    a.nrec = (int)pk[20 * P + p];
+    finalize_lane(a, P, p, C, cov, o);
+}
+
 // Compact call list, sharded: a returning atomic on ONE word serialises at ~11 ns per add (about 90 per us chip-wide,
 // MI355X_MICROARCH.md "dequeue"), which at a few thousand calls per launch would bound the whole kernel.  The list is
 // therefore AMPLI_CALL_SHARDS independent segments, each with its own counter on its own 128-byte line; a workgroup
@@ -1299,7 +1365,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
                              const FinOut &fin)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate))
+    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate) || (fin.packed && !d_acc))
         return fail(ctx, AMPLI_E_INVALID, "error_reduce: bad argument (P,S>0, cov>=1, table bound with ampli_acc_bind for the same P)");
     if (E > 0 && !d_dup_off) return fail(ctx, AMPLI_E_INVALID, "error_reduce: E > 0 needs dup_off");
     if (((uintptr_t)d_recs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned");
@@ -1344,6 +1410,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         out_base = (char *)ctx->ws;
         stride = off[8];
         kfin.rate = nullptr;
+        kfin.packed = nullptr; // packed after the merge, below
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                                                                                       \
@@ -1369,6 +1436,12 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
                            off[6], off[7]);
         rc = check_launch(ctx, "acc_merge_kernel");
         if (rc) return rc;
+        if (fin.packed) {
+            hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc),
+                               (long long)P, fin.packed);
+            rc = check_launch(ctx, "acc_pack_kernel");
+            if (rc) return rc;
+        }
         if (fin.rate) {
             AccPtrs t;
             t.snt = (double *)(merged + off[0]); t.srd = (long long *)(merged + off[1]); t.cnt = (int *)(merged + off[2]);
@@ -1384,7 +1457,7 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
                                   int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc)
 {
     if (!d_acc) return ctx ? fail(ctx, AMPLI_E_INVALID, "error_reduce: d_acc is required") : AMPLI_E_INVALID;
-    FinOut none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    FinOut none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, d_acc, none);
 }
 
@@ -1395,8 +1468,35 @@ extern "C" int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64
 {
     if (!ctx) return AMPLI_E_INVALID;
     if (!d_rate || !d_code) return fail(ctx, AMPLI_E_INVALID, "error_estimate: rate and code outputs are required");
-    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags};
+    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
     return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, 0, C, cov, d_acc, fo);
+}
+
+extern "C" int ampli_error_reduce_packed(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                                         int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc,
+                                         double *d_packed)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_acc || !d_packed) return fail(ctx, AMPLI_E_INVALID, "error_reduce_packed: table and packed buffer are required");
+    FinOut fo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_packed};
+    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, d_acc, fo);
+}
+
+extern "C" int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const double *d_packed, const void *d_gm_regions,
+                                           int32_t nparts, float C, int32_t cov, float *d_rate, uint8_t *d_code, float *d_thr,
+                                           float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (P <= 0 || !d_packed || !d_gm_regions || nparts < 1 || !d_rate || !d_code || cov < 1)
+        return fail(ctx, AMPLI_E_INVALID, "error_finalize_merged: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t off[9];
+    acc_offsets(P, off);
+    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
+    hipLaunchKernelGGL(error_finalize_merged_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_packed,
+                       (const char *)d_gm_regions, off[8] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, (long long)P, C,
+                       (int)cov, fo);
+    return check_launch(ctx, "error_finalize_merged_kernel");
 }
 
 extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_acc_table *d_parts, int32_t nparts)
@@ -1474,7 +1574,7 @@ extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc
     if (!d_acc || d_acc->P <= 0 || !d_rate || !d_code || cov < 1) return fail(ctx, AMPLI_E_INVALID, "error_finalize: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long P = d_acc->P;
-    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags};
+    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
     return launch_finalize(ctx, to_ptrs(d_acc), P, C, (int)cov, fo);
 }
 

@@ -78,11 +78,14 @@ class TableMerger:
         self.packed = [torch.empty(21 * P, dtype=torch.float64, device=device) for _ in range(2)]
         self.gathered = [torch.empty(world * self.gm_bytes, dtype=torch.uint8, device=device) for _ in range(2)]
 
-    def start(self, acc, slot: int):
+    def start(self, acc, slot: int, prepacked: bool = False):
+        """prepacked: packed[slot] was already filled by ampli_error_reduce_packed (no pack launch)."""
         import torch.distributed as dist
 
         P, pk = self.P, self.packed[slot]
-        if self.pack is not None:
+        if prepacked:
+            pass
+        elif self.pack is not None:
             self.pack(acc, pk)
         else:
             pk[0:8 * P].copy_(acc.snt.view(-1))
@@ -93,6 +96,12 @@ class TableMerger:
                                           group=self.group, async_op=True)
         w_r = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return (w_r, w_g)
+
+    def wait(self, handle):
+        """Compute stream waits for both collectives; packed[slot] / gathered[slot] are then ready for
+        ampli_error_finalize_merged (no unpack, no table update)."""
+        for h in handle:
+            h.wait()
 
     def finish(self, acc, slot: int, handle):
         P, pk = self.P, self.packed[slot]

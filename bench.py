@@ -211,15 +211,15 @@ def main():
             ctx.record(ev[i][0])
         if world == 1:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
             fins[i & 1] = fin = ctx.error_estimate(normals, P, 0.002, 100, out=fins[i & 1])
-        else:
-            ctx.error_reduce(normals, P, 0.002, 100, first_sample=rank * S, acc=accs[slot])
+        else:  # shard of a multi-GPU panel: sums straight into the all-reduce buffer, gm planes into the table
+            ctx.error_reduce_packed(normals, P, accs[slot], merger.packed[slot], 0.002, 100, first_sample=rank * S)
         if timed:
             ctx.record(ev[i][1])
 
     def call_part(i, timed, slot):
         nonlocal fin
-        if world > 1:
-            fins[i & 1] = fin = ctx.error_finalize(accs[slot], 0.002, 100, out=fins[i & 1])
+        if world > 1:  # finalize straight from the all-reduced sums + gathered germ-max regions
+            fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
         if timed:
             ctx.record(ev[i][2])
         ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
@@ -242,14 +242,14 @@ def main():
         for i in range(n):
             slot = i & 1
             reduce_part(i, timed, slot)
-            h = merger.start(accs[slot], slot)
+            h = merger.start(accs[slot], slot, prepacked=True)
             if pending is not None:
                 j, pslot, ph = pending
-                merger.finish(accs[pslot], pslot, ph)
+                merger.wait(ph)
                 call_part(j, timed, pslot)
             pending = (i, slot, h)
         j, pslot, ph = pending
-        merger.finish(accs[pslot], pslot, ph)
+        merger.wait(ph)
         call_part(j, timed, pslot)
 
     def fence():
@@ -263,22 +263,17 @@ def main():
     if world > 1 and args.check:
         # every shard regenerated locally and reduced in one pass must equal the merged table, bit for bit
         allrecs = torch.cat([ctx.synth_fill(P, S, first_sample=k * S, seed=SEED, depth=depth) for k in range(world)])
-        ref = ctx.error_reduce(allrecs, P, 0.002, 100)
-        for name, plane in ref.planes().items():
-            got = accs[(args.warmup - 1) & 1].planes()[name]
-            if name in ("gm_first", "gm_first_af"):
-                sel = ref.gm_n > 0
-                ok = torch.equal(plane[sel], got[sel])
-            elif name == "gm_rest":
-                sel = ref.gm_n > 1
-                ok = torch.equal(plane[sel], got[sel])
-            else:
-                ok = torch.equal(plane, got)
+        ref = ctx.error_estimate(allrecs, P, 0.002, 100)
+        got = fins[(args.warmup - 1) & 1]
+        present = ref.germ_present > 0
+        for name, ok in (("rate", torch.equal(ref.rate, got.rate)), ("code", torch.equal(ref.code, got.code)),
+                         ("thr", torch.equal(ref.thr, got.thr)), ("germ_present", torch.equal(ref.germ_present, got.germ_present)),
+                         ("germ_val", torch.equal(ref.germ_val[present], got.germ_val[present]))):
             if not ok:
-                raise SystemExit(f"rank {rank}: merged table differs from the single-pass table in plane {name}")
+                raise SystemExit(f"rank {rank}: merged error table differs from the single-pass one in {name}")
         del allrecs, ref
         if rank == 0:
-            print("check: merged accumulator table == single-pass table on every plane", file=sys.stderr)
+            print("check: merged error table == single-pass error table (rate, code, thr, germ-max), bit for bit", file=sys.stderr)
         fence()
     t0 = time.perf_counter()
     run_steps(args.steps, True)

@@ -165,6 +165,17 @@ int64_t ampli_acc_packed_len(int64_t P);
 int ampli_acc_pack(ampli_ctx *ctx, const ampli_acc_table *d_acc, double *d_packed);
 int ampli_acc_unpack(ampli_ctx *ctx, const double *d_packed, const ampli_acc_table *d_acc);
 
+/* Multi-GPU fast path (same results as reduce -> pack ... unpack -> gm_merge -> finalize, two launches fewer and no
+ * table round trip): error_reduce_packed writes a shard's additive planes straight into the all-reduce buffer
+ * (d_acc then only receives the germ-max planes, for the all-gather); error_finalize_merged finalises from the
+ * all-reduced buffer and the gathered germ-max regions (rank order = sample order). */
+int ampli_error_reduce_packed(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                              int32_t S, int32_t first_sample, float C, int32_t coverage_cutoff,
+                              const ampli_acc_table *d_acc, double *d_packed);
+int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const double *d_packed, const void *d_gm_regions,
+                                int32_t nparts, float C, int32_t coverage_cutoff, float *d_rate, uint8_t *d_code,
+                                float *d_thr, float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
+
 /* gm_merge -- fold nparts gathered gm regions (region k = shard k, ascending sample order, laid out
  * back to back, gm_bytes each) into d_dst's germ-max planes.  The sequential state machine of
  * EE:1251-1271 composes over shards exactly as ampli_acc_merge does. */

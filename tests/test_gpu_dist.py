@@ -19,7 +19,7 @@ def test_bench_multirank_path_on_one_gpu(world):
            "--backend", "gloo", "--check", "--config", "c2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "check: merged accumulator table == single-pass table on every plane" in r.stderr
+    assert "check: merged error table == single-pass error table" in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d

@@ -480,3 +480,30 @@ def test_shard_count_invariance(ctx, shards):
     ctx.gm_merge(dst, gathered, shards)
     assert_acc_equal(dst, full)
     assert_final_equal(ctx.error_finalize(dst), orc.error_finalize(full))
+
+
+@pytest.mark.parametrize("shards,S", [(2, 40), (4, 67), (8, 300)])
+def test_packed_shard_path_equals_single_pass(ctx, shards, S):
+    """The multi-GPU fast path: error_reduce_packed per shard, SUM of the packed buffers (= the all-reduce), gm regions
+    in rank order (= the all-gather), error_finalize_merged  ==  the oracle's single pass.  S = 300 also exercises the
+    internal sample split (partial tables -> merge -> pack)."""
+    import torch
+
+    from amplisolve_amd.dist import shard_range
+
+    P = 2500
+    recs = synth_recs(P, S)
+    ref = orc.error_finalize(orc.error_reduce(recs, P))
+    d_recs = _t(recs)
+    _, gm_off, gm_bytes = ctx.regions(P)
+    packed, regions = [], []
+    for r in range(shards):
+        lo, hi = shard_range(S, r, shards)
+        acc = ctx.new_acc(P)
+        pk = torch.empty(21 * P, dtype=torch.float64, device="cuda")
+        ctx.error_reduce_packed(d_recs[lo:hi].contiguous(), P, acc, pk, first_sample=lo)
+        packed.append(pk)
+        regions.append(acc.buf[gm_off: gm_off + gm_bytes].clone())
+    fin = ctx.error_finalize_merged(P, torch.stack(packed).sum(0), torch.cat(regions), shards)
+    assert_final_equal(fin, ref)
+    assert ctx.flags() == 0
