@@ -73,6 +73,10 @@ HIP_SYMBOLS = {
     "ampli_set_tuning": (C.c_int, [vp, i32, i32]),
     "ampli_ctx_flags": (C.c_int, [vp, C.POINTER(i32), i32]),
     "ampli_set_queue_items": (C.c_int, [vp, i64]),
+    "ampli_graph_begin": (C.c_int, [vp]),
+    "ampli_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "ampli_graph_launch": (C.c_int, [vp, vp]),
+    "ampli_graph_destroy": (C.c_int, [vp]),
     "ampli_set_async_drain": (C.c_int, [vp, i32]),
     "ampli_wait_calls": (C.c_int, [vp]),
 }

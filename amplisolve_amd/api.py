@@ -119,6 +119,21 @@ class Context:
     def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
         self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general) | (groups << 4)))
 
+    # ---- hipGraph capture ---------------------------------------------------------------
+    def graph_begin(self):
+        self._check(self.lib.ampli_graph_begin(self.h))
+
+    def graph_end(self):
+        g = C.c_void_p()
+        self._check(self.lib.ampli_graph_end(self.h, C.byref(g)))
+        return g
+
+    def graph_launch(self, g):
+        self._check(self.lib.ampli_graph_launch(self.h, g))
+
+    def graph_destroy(self, g):
+        self.lib.ampli_graph_destroy(g)
+
     def set_async_drain(self, on: bool):
         """poisson_call's drain kernel on a side stream; results complete after wait_calls() / sync()."""
         self._check(self.lib.ampli_set_async_drain(self.h, int(on)))

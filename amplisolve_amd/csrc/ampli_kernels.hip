@@ -160,6 +160,54 @@ extern "C" int ampli_wait_calls(ampli_ctx *ctx)
     return join_drain(ctx);
 }
 
+// ---------------------------------------------------------------------------
+// hipGraph capture of a sequence of ampli_* calls (launch-bound small panels: a pass over a 10k-position panel is
+// four ~10 us kernels, so the launches themselves dominate).  Capture needs a real stream (AMPLI_STREAM_OWN or any
+// non-null stream) and warm workspaces: run the sequence once before capturing; a call that would have to allocate
+// or synchronise while capturing fails with AMPLI_E_INVALID.
+// ---------------------------------------------------------------------------
+static bool is_capturing(ampli_ctx *ctx)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (!ctx->stream) return false;
+    if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess) return false;
+    return st == hipStreamCaptureStatusActive;
+}
+
+extern "C" int ampli_graph_begin(ampli_ctx *ctx)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!ctx->stream) return fail(ctx, AMPLI_E_INVALID, "graph capture needs a non-default stream (AMPLI_STREAM_OWN)");
+    { int rc = join_drain(ctx); if (rc) return rc; }
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_graph_end(ampli_ctx *ctx, void **graph_exec)
+{
+    if (!ctx || !graph_exec) return AMPLI_E_INVALID;
+    hipGraph_t g = nullptr;
+    HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (err != hipSuccess) return fail(ctx, AMPLI_E_HIP, "hipGraphInstantiate failed");
+    *graph_exec = (void *)e;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_graph_launch(ampli_ctx *ctx, void *graph_exec)
+{
+    if (!ctx || !graph_exec) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_graph_destroy(void *graph_exec)
+{
+    return hipGraphExecDestroy((hipGraphExec_t)graph_exec) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP;
+}
+
 extern "C" int ampli_sync(ampli_ctx *ctx)
 {
     if (!ctx) return AMPLI_E_INVALID;
@@ -1326,6 +1374,7 @@ static int check_launch(ampli_ctx *ctx, const char *what)
 static int ensure_ws(ampli_ctx *ctx, size_t bytes)
 {
     if (ctx->ws_bytes >= bytes) return AMPLI_OK;
+    if (is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "workspace would have to grow while capturing: run the sequence once first");
     if (ctx->ws) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     if (hipMalloc(&ctx->ws, bytes) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "workspace hipMalloc failed");
     ctx->ws_bytes = bytes;
@@ -1507,6 +1556,7 @@ extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, con
     for (int i = 0; i < nparts; ++i)
         if (d_parts[i].P != P) return fail(ctx, AMPLI_E_INVALID, "acc_merge: part table P mismatch");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "acc_merge cannot be captured (it uploads a pointer list)");
     int rc = ensure_ws(ctx, sizeof(AccPtrs) * 64);
     if (rc) return rc;
     AccPtrs hp[64];
@@ -1625,6 +1675,10 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         const size_t slack = (size_t)AMPLI_CALL_SHARDS * 256 * 3 * (size_t)rows;
         if (ctx->queue_min_items) want = std::max(want, ctx->queue_min_items + slack);
         want = (want + AMPLI_CALL_SHARDS - 1) / AMPLI_CALL_SHARDS * AMPLI_CALL_SHARDS;
+        const bool capturing = is_capturing(ctx);
+        if ((ctx->queue_items < want || !ctx->queue_n) && capturing)
+            return fail(ctx, AMPLI_E_INVALID, "queue would have to be allocated while capturing: run the sequence once first");
+        if (ctx->async_drain && capturing) return fail(ctx, AMPLI_E_INVALID, "asynchronous drain cannot be captured");
         if (ctx->queue_items < want) {
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (ctx->queue) (void)hipFree(ctx->queue);
@@ -1641,7 +1695,10 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         const long long per = (long long)(ctx->queue_items / AMPLI_CALL_SHARDS);
         unsigned long long *qn = ctx->queue_n + (size_t)(ctx->queue_parity & 1) * AMPLI_CALL_COUNTER_WORDS;
         unsigned long long *qn_next = ctx->queue_n + (size_t)((ctx->queue_parity + 1) & 1) * AMPLI_CALL_COUNTER_WORDS;
-        ctx->queue_parity ^= 1;
+        if (capturing) // a replayed graph cannot alternate halves: reset the half it uses with a memset node instead
+            HIP_TRY(ctx, hipMemsetAsync(qn, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
+        else
+            ctx->queue_parity ^= 1;
         dim3 qgrid((unsigned)tiles, (unsigned)gy);
         hipLaunchKernelGGL(poisson_stream_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P, (long long)E,
                            d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,

@@ -246,6 +246,14 @@ int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_
 int ampli_set_async_drain(ampli_ctx *ctx, int32_t on);
 int ampli_wait_calls(ampli_ctx *ctx);
 
+/* hipGraph capture of a sequence of calls on the context's stream (small, launch-bound panels).  The context must
+ * own a real stream (AMPLI_STREAM_OWN or a non-null stream) and the sequence must have run once (workspaces warm).
+ * ampli_graph_end returns a hipGraphExec_t as an opaque pointer; launch it any number of times. */
+int ampli_graph_begin(ampli_ctx *ctx);
+int ampli_graph_end(ampli_ctx *ctx, void **graph_exec);
+int ampli_graph_launch(ampli_ctx *ctx, void *graph_exec);
+int ampli_graph_destroy(void *graph_exec);
+
 /* scalar scorer on the device for known-answer tests: q[i] = score(k[i], rd[i], err[i]),
  * p[i] = 1 - kf_gammaq(k, rd*err) (VC:3834-3884).  Either output may be NULL. */
 int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err,

@@ -507,3 +507,61 @@ def test_packed_shard_path_equals_single_pass(ctx, shards, S):
     fin = ctx.error_finalize_merged(P, torch.stack(packed).sum(0), torch.cat(regions), shards)
     assert_final_equal(fin, ref)
     assert ctx.flags() == 0
+
+
+def test_hipgraph_capture_replays_the_same_pass():
+    """A whole pass (error_estimate -> poisson_call) captured into a hipGraph on the context's own stream and
+    replayed gives the same table, mask and calls as the eager pass (small, launch-bound panel)."""
+    import time
+
+    import torch
+
+    from amplisolve_amd import Context
+    from amplisolve_amd.api import POISSON_PREFILTER
+
+    g_ctx = Context(0, own_stream=True)
+    P, S, T = 10_000, 32, 8
+    normals = g_ctx.synth_fill(P, S)
+    tum = g_ctx.synth_fill(P, T, tumour=True)
+    refc = g_ctx.synth_ref(P)
+    g_ctx.sync()
+    fin = g_ctx.error_estimate(normals, P)
+    res = g_ctx.poisson_call(tum, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 16)
+    g_ctx.sync()
+    eager_mask = res["call_mask"].clone()
+    eager_thr = fin.thr.clone()
+    eager_calls = g_ctx.read_calls(res)
+    torch.cuda.synchronize()
+
+    def one_pass():
+        g_ctx.error_estimate(normals, P, out=fin)
+        g_ctx.poisson_call(tum, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, call_mask=res["call_mask"], capacity=res["capacity"],
+                           calls_buf=res["calls_buf"], n_calls=res["n_calls"])
+
+    g_ctx.graph_begin()
+    one_pass()
+    graph = g_ctx.graph_end()
+    res["call_mask"].zero_(); fin.thr.zero_()
+    torch.cuda.synchronize()
+    for _ in range(3):
+        g_ctx.graph_launch(graph)
+    g_ctx.sync()
+    assert torch.equal(res["call_mask"], eager_mask) and torch.equal(fin.thr, eager_thr)
+    calls = g_ctx.read_calls(res)
+    assert len(calls) == len(eager_calls) > 0 and np.array_equal(calls["record"], eager_calls["record"])
+    # launch-bound shape: replaying the graph must not be slower than enqueueing the four kernels one by one
+    n = 200
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one_pass()
+    g_ctx.sync()
+    t_eager = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    for _ in range(n):
+        g_ctx.graph_launch(graph)
+    g_ctx.sync()
+    t_graph = (time.perf_counter() - t0) / n
+    print(f"config-2 pass: eager {t_eager*1e6:.1f} us, hipGraph replay {t_graph*1e6:.1f} us")
+    assert t_graph < 1.5 * t_eager
+    g_ctx.graph_destroy(graph)
+    g_ctx.close()
