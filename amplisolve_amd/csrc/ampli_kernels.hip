@@ -471,7 +471,7 @@ struct AccPtrs {
     double *snt; long long *srd; int *cnt; int *nrec; int *gm_n; int *gm_first; float *gm_first_af; float *gm_rest;
 };
 
-__device__ __forceinline__ AccPtrs acc_at(char *base, long long P, size_t o0, size_t o1, size_t o2, size_t o3,
+__device__ __forceinline__ AccPtrs acc_at(char *base, long long /*P*/, size_t o0, size_t o1, size_t o2, size_t o3,
                                           size_t o4, size_t o5, size_t o6, size_t o7)
 {
     AccPtrs a;
@@ -892,8 +892,6 @@ __global__ __launch_bounds__(256) void acc_merge_kernel(char *dst_base, const ch
 }
 
 // merge of arbitrary (non-strided) part tables: pointers passed through a small device array
-struct PartPtrs { AccPtrs t[1]; };
-
 __global__ __launch_bounds__(256) void acc_merge_ptr_kernel(AccPtrs dst, const AccPtrs *parts, const int nparts,
                                                             const long long P)
 {

@@ -53,7 +53,7 @@ const uint8_t *ampli_host_cohort_dup_flag(const ampli_host_cohort *h);/* [P] */
 const char *ampli_host_cohort_sample_name(const ampli_host_cohort *h, int32_t s);
 void ampli_host_cohort_stats(const ampli_host_cohort *h, int64_t *lines, int64_t *offpanel, int64_t *irregular, int64_t *malformed);
 int ampli_host_position(const ampli_host_cohort *h, int64_t p, char *chrom_out, int chrom_cap, int32_t *coord);
-/* sample names of dir/*.ASEQ in visit order, newline separated; returns the count */
+/* sample names of the .ASEQ files of dir in visit order, newline separated; returns the count */
 int ampli_host_sample_order(const char *dir, char *out, int64_t cap);
 
 /* ---- the error table on disk (EE:2546-2944 writer, VC:430-576 reader) ---- */
