@@ -1,10 +1,14 @@
 // amplisolve_amd/csrc/ampli_kernels.hip -- HIP kernels + C ABI of libamplisolve_hip.so (gfx950, wave64).
 //
-// Kernels (all HBM-bound integer / scalar-FP work, no MFMA):
-//   error_reduce_kernel   EE:1149-1296 (+clones), EE:1565-1631 (+clones)   32 B read per (position, sample)
-//   acc_merge_kernel      ordered combine of partial accumulator tables
-//   error_finalize_kernel EE:1659-1714 (+clones), sentinel rule EE:1260/1318/1374/1431, text round trip EE:1704->VC:889
-//   poisson_call_kernel   VC:752-898 (+clones), VC:3721-3884                32 B read per (position, tumour)
+// Kernels (HBM-bound integer / scalar-FP work, no MFMA):
+//   error_reduce_kernel<FAST,G>   EE:1149-1296 (+clones), EE:1565-1631 (+clones)      32 B read per (position, sample);
+//                                 optional fused epilogue = finalize_lane, or packed sums for the multi-GPU merge
+//   acc_merge_kernel / acc_merge_ptr_kernel / gm_merge_kernel   ordered combines of partial accumulator tables
+//   acc_pack_kernel / acc_unpack_kernel                         additive planes <-> one float64 all-reduce buffer
+//   error_finalize_kernel / error_finalize_merged_kernel        EE:1659-1714 (+clones), sentinel rule EE:1260/1318/1374/1431,
+//                                                               text round trip EE:1704 -> VC:889
+//   poisson_stream_kernel + poisson_drain_kernel   VC:752-898 (+clones), VC:3721-3884   32 B read per (position, tumour)
+//   poisson_call_kernel<MODE>                      the same evaluated in place (validation mode, dense outputs)
 // See include/amplisolve_hip.h for the data layout and DESIGN.md for the rooflines.
 #include <hip/hip_runtime.h>
 
@@ -1116,7 +1120,7 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 // ---------------------------------------------------------------------------
 // poisson_call, prefilter mode = two kernels.
 //
-// poisson_stream_kernel: one lane per position, PCS_SAMPLES tumour rows per workgroup; thresholds, reference
+// poisson_stream_kernel: one lane per position, a few tumour rows per workgroup; thresholds, reference
 //   code and the derived per-position constants stay in registers across the rows.  Most (record, alt) pairs are
 //   settled by a conservative fp32 form of the exact bound "k <= m = RD*err => Q < 5" (ampli_prefilter_nocall):
 //       skip  <=>  float(k) <= (float(RD) * 0.999999f) * err_eff

@@ -169,7 +169,7 @@ AMPLI_FN double ampli_poisson_score(int32_t k, int32_t rd, float err)
 // Exact-decision bound used by AMPLI_POISSON_PREFILTER: when k <= m the
 // reference's own scorer returns Q < 5 (P(X >= k) > 0.31 for k <= mean; checked
 // exhaustively against the scorer incl. its iteration caps in
-// tests/test_prefilter.py), so VC:898 is false whatever the other strand says.
+// tests/test_math_host.py), so VC:898 is false whatever the other strand says.
 // err == -1 gives Q = -888 < 5 as well.
 AMPLI_FN int ampli_prefilter_nocall(int32_t k, int32_t rd, float err)
 {
