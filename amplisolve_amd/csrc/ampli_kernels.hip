@@ -601,7 +601,7 @@ __device__ __forceinline__ void finalize_lane(const LaneAcc &a, const long long 
 // Fast per-lane state (the shipped inner loop).  Same results as LaneAcc /
 // visit_record, fewer instructions per record:
 //   * the qualifying sums are kept as an integer part (sum of X, sum of depth,
-//     int32: a wave never sees more than 64 samples) and a double part (sum of
+//     int32 / int64) and a double part (sum of
 //     the fp32 products); snt = (double)sumX + sumP is exact inside the
 //     envelope of DESIGN.md section 4, like every other association;
 //   * Germ_Max needs max over records of RN(x/d); RN is monotone, so the
@@ -612,12 +612,12 @@ __device__ __forceinline__ void finalize_lane(const LaneAcc &a, const long long 
 // raises AMPLI_FLAG_RERUN_GENERAL and the caller reruns the literal kernel.
 // ---------------------------------------------------------------------------
 constexpr int FAST_COUNT_LIMIT = 1 << 22;
-constexpr int FAST_MAX_CHUNK = 64;        // samples per wave (int32 sums: 64 x (1+extras) x 2^22 < 2^31 for <= 7 extras)
-constexpr int FAST_MAX_RECORDS = 511;     // records per wave and position before the int32 sums could wrap
+constexpr int FAST_MAX_CHUNK = 1024;      // samples per lane: sum of X (<= 0.05 x 2^22 each) stays below 2^31 for 8191 records
+constexpr int FAST_MAX_RECORDS = 8191;    // records per lane (samples x (1 + extras)) before the int32 sum of X could wrap
 
 struct FastAcc {
     int sx[2][4];     // sum of X over qualifying records
-    int sd[2][4];     // sum of strand depth over qualifying records
+    long long sd[2][4]; // sum of strand depth over qualifying records
     double sp[2][4];  // sum of float(depth)*float(C) over qualifying records
     int cnt[4];
     int nrec;
