@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splits", type=int, default=0, help="error_reduce sample splits (0 = auto)")
     ap.add_argument("--groups", type=int, default=0, help="error_reduce lane groups per wave (0 = auto, 1, 2, 4)")
+    ap.add_argument("--event-every", type=int, default=5, help="record the per-kernel HIP events on every n-th timed step (each record costs a few us of stream time)")
+    ap.add_argument("--streams", type=int, default=1, help="N = 1 only: independent batches round-robin over this many HIP streams "
+                    "(cross-batch overlap; per-kernel times then include contention, so the default stays 1)")
     ap.add_argument("--async-drain", action="store_true", help="poisson_call's drain kernel on a side stream (measured: no gain on config 3)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
@@ -171,6 +174,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
+    # everything (kernels, torch plumbing, RCCL's stream dependencies) hangs off ONE non-default stream: the legacy
+    # null stream carries implicit synchronisation that costs a few us per launch
+    main_stream = torch.cuda.Stream(device=dev_index)
+    torch.cuda.set_stream(main_stream)
     ctx = Context(dev_index)
     if args.splits or args.groups:
         ctx.set_tuning(args.splits, groups=args.groups)
@@ -198,6 +205,7 @@ def main():
     merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack) if world > 1 else None
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
+    ev_steps = [i for i in range(args.steps) if i % max(1, args.event_every) == 0]
 
     # two error tables, used alternately: with the asynchronous drain the survivors of batch i are still being scored
     # (reading batch i's thresholds) while batch i+1's table is being written
@@ -207,6 +215,7 @@ def main():
 
     def reduce_part(i, timed, slot):
         nonlocal fin
+        timed = timed and i % max(1, args.event_every) == 0
         if timed:
             ctx.record(ev[i][0])
         if world == 1:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
@@ -218,6 +227,7 @@ def main():
 
     def call_part(i, timed, slot):
         nonlocal fin
+        timed = timed and i % max(1, args.event_every) == 0
         if world > 1:  # finalize straight from the all-reduced sums + gathered germ-max regions
             fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
         if timed:
@@ -258,6 +268,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lanes = None
+    if world == 1 and args.streams > 1:
+        # extra lanes: own stream + own outputs each; inputs are shared (read-only)
+        lanes = []
+        for _ in range(args.streams):
+            st = torch.cuda.Stream(device=dev_index)
+            with torch.cuda.stream(st):
+                c = Context(dev_index)
+                f = c.error_estimate(normals, P, 0.002, 100)
+                r = c.poisson_call(tumours, P, f.thr, ref_code, 100, mode=mode, capacity=cap)
+            lanes.append((c, f, r))
+        torch.cuda.synchronize()
+
+        def run_steps(n, timed):  # noqa: F811  (replaces the single-stream loop)
+            for i in range(n):
+                c, f, r = lanes[i % len(lanes)]
+                t = timed and i % max(1, args.event_every) == 0
+                if t:
+                    c.record(ev[i][0])
+                c.error_estimate(normals, P, 0.002, 100, out=f)
+                if t:
+                    c.record(ev[i][1])
+                    c.record(ev[i][2])
+                c.poisson_call(tumours, P, f.thr, ref_code, 100, mode=mode, call_mask=r["call_mask"], capacity=r["capacity"],
+                               calls_buf=r["calls_buf"], n_calls=r["n_calls"])
+                if t:
+                    c.record(ev[i][3])
+
     run_steps(args.warmup, False)
     fence()
     if world > 1 and args.check:
@@ -284,9 +322,11 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    t_red = sum(ctx.elapsed_ms(e[0], e[1]) for e in ev) / args.steps
-    t_call_main = sum(ctx.elapsed_ms(e[2], e[3]) for e in ev) / args.steps  # main-stream part (all of it unless --async-drain)
+    t_red = sum(ctx.elapsed_ms(ev[i][0], ev[i][1]) for i in ev_steps) / len(ev_steps)
+    t_call_main = sum(ctx.elapsed_ms(ev[i][2], ev[i][3]) for i in ev_steps) / len(ev_steps)  # main-stream part (all of it unless --async-drain)
     ctx.wait_calls()
+    if lanes is not None:
+        n_calls, fin = lanes[0][2]["n_calls"], lanes[0][1]
     n_found = int(n_calls[::CALL_COUNTER_STRIDE].sum().item())
     # the whole poisson_call (stream + drain kernels back to back), outside the timed region
     ctx.set_async_drain(False)
@@ -350,7 +390,7 @@ def main():
             "dtype": "int32 counts; f64 sums / Poisson; f32 rates",
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "depth": depth,
-                       "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode,
+                       "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if world == 1 else 1,
                        "parallelism": f"tumour+normal sample shards x{world}" + ("; one packed RCCL all-reduce + all-gather of the error table per batch, overlapped with the neighbouring batches" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
