@@ -335,10 +335,12 @@ static void acc_offsets(int64_t P, size_t off[9])
     off[1] = o; o = align_up(o + (size_t)P * 8 * sizeof(int64_t), 256);  // srd
     off[2] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // cnt
     off[3] = o; o = align_up(o + (size_t)P * 1 * sizeof(int32_t), 256);  // nrec
+    // memory order: gm_n | gm_first_af | gm_rest | gm_first -- the first three are what shards exchange (the "gm
+    // region"); gm_first is bookkeeping and stays local
     off[4] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // gm_n
-    off[5] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // gm_first
     off[6] = o; o = align_up(o + (size_t)P * 4 * sizeof(float), 256);    // gm_first_af
     off[7] = o; o = align_up(o + (size_t)P * 4 * sizeof(float), 256);    // gm_rest
+    off[5] = o; o = align_up(o + (size_t)P * 4 * sizeof(int32_t), 256);  // gm_first
     off[8] = o;
 }
 
@@ -942,9 +944,8 @@ __global__ __launch_bounds__(256) void acc_unpack_kernel(AccPtrs t, const long l
 // germ-max triples only.  regions: nparts copies of the gm region of a table (gm_n .. end of gm_rest),
 // region k at regions + k*stride; plane offsets inside a region as in the table.
 __global__ __launch_bounds__(256) void gm_merge_kernel(int *gm_n, int *gm_first, float *gm_first_af, float *gm_rest,
-                                                       const char *regions, const size_t stride, const size_t of,
-                                                       const size_t ofa, const size_t orr, const int nparts,
-                                                       const long long P)
+                                                       const char *regions, const size_t stride, const size_t ofa,
+                                                       const size_t orr, const int nparts, const long long P)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; // over 4*P
     if (i >= 4 * P) return;
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(256) void gm_merge_kernel(int *gm_n, int *gm_first,
         if (rn == 0) continue;
         const float fa = ((const float *)(b + ofa))[i], rr = ((const float *)(b + orr))[i];
         if (n == 0) {
-            first = ((const int *)(b + of))[i]; first_af = fa; rest = rr;
+            first = -1; first_af = fa; rest = rr; // the sample index is not exchanged: unknown after a gathered merge
         } else {
             if (rest <= fa) rest = fa;
             if (rest <= rr) rest = rr;
@@ -1545,7 +1546,7 @@ extern "C" int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const doub
     acc_offsets(P, off);
     FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
     hipLaunchKernelGGL(error_finalize_merged_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_packed,
-                       (const char *)d_gm_regions, off[8] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, (long long)P, C,
+                       (const char *)d_gm_regions, off[5] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, (long long)P, C,
                        (int)cov, fo);
     return check_launch(ctx, "error_finalize_merged_kernel");
 }
@@ -1598,9 +1599,9 @@ extern "C" int ampli_acc_regions(int64_t P, size_t *sum_bytes, size_t *gm_offset
     if (P <= 0) return AMPLI_E_INVALID;
     size_t off[9];
     acc_offsets(P, off);
-    if (sum_bytes) *sum_bytes = off[5]; // snt|srd|cnt|nrec|gm_n
+    if (sum_bytes) *sum_bytes = off[6]; // snt|srd|cnt|nrec|gm_n
     if (gm_offset) *gm_offset = off[4];
-    if (gm_bytes) *gm_bytes = off[8] - off[4];
+    if (gm_bytes) *gm_bytes = off[5] - off[4]; // gm_n|gm_first_af|gm_rest
     return AMPLI_OK;
 }
 
@@ -1613,8 +1614,8 @@ extern "C" int ampli_gm_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, cons
     size_t off[9];
     acc_offsets(P, off);
     hipLaunchKernelGGL(gm_merge_kernel, dim3((unsigned)((4 * P + 255) / 256)), dim3(256), 0, ctx->stream, d_dst->gm_n,
-                       d_dst->gm_first, d_dst->gm_first_af, d_dst->gm_rest, (const char *)d_regions, off[8] - off[4],
-                       off[5] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, P);
+                       d_dst->gm_first, d_dst->gm_first_af, d_dst->gm_rest, (const char *)d_regions, off[5] - off[4],
+                       off[6] - off[4], off[7] - off[4], (int)nparts, P);
     return check_launch(ctx, "gm_merge_kernel");
 }
 

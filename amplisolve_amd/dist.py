@@ -92,9 +92,10 @@ class TableMerger:
             pk[8 * P:16 * P].copy_(acc.srd.view(-1))
             pk[16 * P:20 * P].copy_(acc.cnt.view(-1))
             pk[20 * P:21 * P].copy_(acc.nrec)
+        # the all-reduce is the critical one (the thresholds hang on it): issue it first
+        w_r = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         w_g = dist.all_gather_into_tensor(self.gathered[slot], acc.buf[self.gm_off: self.gm_off + self.gm_bytes],
                                           group=self.group, async_op=True)
-        w_r = dist.all_reduce(pk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return (w_r, w_g)
 
     def wait(self, handle):

@@ -93,13 +93,15 @@ int ampli_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchro
  * Accumulator table: what storeGermlineStatistics + the record loop of
  * estimateThresholds leave behind per (position, nucleotide), as planes with the
  * position index fastest.  All planes live in one buffer of ampli_acc_bytes(P)
- * bytes; ampli_acc_bind carves the pointers.  Plane order in the buffer:
+ * bytes; ampli_acc_bind carves the pointers (buffer order: snt, srd, cnt, nrec, gm_n, gm_first_af, gm_rest,
+ * gm_first).  The planes:
  *   snt  double [2][4][P]  sum of X_s + float(RD_s)*float(C) over qualifying records   (EE:1597,1599)
  *   srd  int64  [2][4][P]  sum of RD_s over qualifying records                         (EE:1598,1600)
  *   cnt  int32  [4][P]     qualifying records                                          (EE:1606)
  *   nrec int32  [P]        all records of the position = Value_Hash.count(key)         (EE:1659)
  *   gm_n int32  [4][P]     records qualifying for Germ_Max                             (EE:1251)
- *   gm_first    int32 [4][P]  global sample index of the first qualifying record (INT32_MAX: none)
+ *   gm_first    int32 [4][P]  global sample index of the first qualifying record (INT32_MAX: none; -1: unknown,
+ *                             after a gathered merge -- bookkeeping only, last plane of the buffer)
  *   gm_first_af float [4][P]  its AF (the reference discards it, EE:1258-1261; kept to merge shards)
  *   gm_rest     float [4][P]  max AF over the later qualifying records (-inf: none)    (EE:1263-1270)
  * [2] = strand (0 forward, 1 reverse), [4] = nucleotide A,C,G,T.
@@ -156,7 +158,7 @@ int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_ac
 
 /* Byte regions of a table buffer for the multi-GPU merge: [0, sum_bytes) holds the planes that merge by
  * addition (snt | srd | cnt | nrec | gm_n; reduce each with its own dtype), [gm_offset, gm_offset+gm_bytes)
- * holds gm_n | gm_first | gm_first_af | gm_rest (all-gather it BEFORE gm_n is reduced). */
+ * holds gm_n | gm_first_af | gm_rest, 48*P bytes (all-gather it BEFORE gm_n is reduced). */
 int ampli_acc_regions(int64_t P, size_t *sum_bytes, size_t *gm_offset, size_t *gm_bytes);
 
 /* The additive planes as ONE float64 buffer [snt 8P | srd 8P | cnt 4P | nrec P] (ampli_acc_packed_len(P) = 21*P

@@ -46,8 +46,11 @@ def test_acc_layout_is_plane_aligned():
     t = _lib.AccTable()
     base = 1 << 20
     assert lib.ampli_acc_bind(C.c_void_p(base), P, C.byref(t)) == 0
-    ptrs = [t.snt, t.srd, t.cnt, t.nrec, t.gm_n, t.gm_first, t.gm_first_af, t.gm_rest]
+    ptrs = [t.snt, t.srd, t.cnt, t.nrec, t.gm_n, t.gm_first_af, t.gm_rest, t.gm_first]  # buffer order
     assert all(p % 256 == 0 for p in ptrs) and ptrs == sorted(ptrs) and ptrs[-1] + 16 * P <= base + n
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    assert lib.ampli_acc_regions(P, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert b.value == t.gm_n - base and b.value + c.value == t.gm_first - base and a.value == t.gm_first_af - base
 
 
 def test_no_gpu_means_loud_failure():
