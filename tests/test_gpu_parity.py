@@ -567,3 +567,32 @@ def test_hipgraph_capture_replays_the_same_pass():
     assert t_graph < 1.5 * t_eager
     g_ctx.graph_destroy(graph)
     g_ctx.close()
+
+
+@pytest.mark.parametrize("name,P,S,T,depth", [("config4", 100_000, 1024, 1024, 2000), ("config5", 1_000_000, 256, 64, 50_000)])
+def test_baseline_configs_4_and_5_full_size(ctx, name, P, S, T, depth):
+    """BASELINE configs 4 and 5 at their FULL sizes on one GPU (6.6 GB / 10 GB of records): exactness flags clear,
+    a slice of the error table and of the call masks equal to the oracle, prefilter == conservation properties."""
+    import torch
+
+    from amplisolve_amd.api import POISSON_PREFILTER
+
+    nor = ctx.synth_fill(P, S, depth=depth)
+    tum = ctx.synth_fill(P, T, depth=depth, tumour=True)
+    refc = ctx.synth_ref(P)
+    fin = ctx.error_estimate(nor, P)
+    res = ctx.poisson_call(tum, P, fin.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 22)
+    assert ctx.flags() == 0 and int(fin.flags.item()) == 0
+    sl = slice(P // 3, P // 3 + 300)
+    o_acc = orc.error_reduce(nor[:, sl].cpu().numpy(), 300)
+    assert o_acc["order_sensitive"] == 0
+    o_fin = orc.error_finalize(o_acc)
+    assert np.array_equal(fin.thr[:, :, sl].cpu().numpy().view(np.int32), o_fin["thr"].view(np.int32))
+    assert np.array_equal(fin.code[:, sl].cpu().numpy(), o_fin["code"])
+    o_call = orc.poisson_call(tum[:8, sl].cpu().numpy(), 300, o_fin["thr"], refc[sl].cpu().numpy(), 100, dense=False)
+    assert np.array_equal(res["call_mask"][:8, sl].cpu().numpy(), o_call["call_mask"])
+    n = ctx.n_calls_total(res)
+    bits = sum(int(((res["call_mask"] >> a) & 1).sum()) for a in range(4))
+    assert n == bits > 0
+    del nor, tum, res, fin
+    torch.cuda.empty_cache()
