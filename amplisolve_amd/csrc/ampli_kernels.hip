@@ -1136,10 +1136,11 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 // it once per 32 items.
 // ---------------------------------------------------------------------------
 
-struct PcItem { // 32 bytes
-    int sample, record, alt_pad;
-    int k_fw, d_fw, k_bw, d_bw;
-    int pad;
+struct PcItem { // 32 bytes, self-contained: the drain kernel needs no second look at the records or the thresholds
+    int sample;
+    int record_alt;             // record | alt << 30
+    int k_fw, d_fw, k_bw, d_bw; // VC:895-896 arguments (d_fw = RD - BW)
+    float e_fw, e_bw;           // effective errors (ampli_effective_err)
 };
 
 __global__ __launch_bounds__(256) void poisson_stream_kernel(
@@ -1241,8 +1242,9 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
                                             __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
                         if (i < queue_per_shard) {
                             PcItem it;
-                            it.sample = t0 + dt; it.record = (int)r; it.alt_pad = nt;
-                            it.k_fw = fw[nt]; it.d_fw = d_fw; it.k_bw = bw[nt]; it.d_bw = d_bw; it.pad = 0;
+                            it.sample = t0 + dt; it.record_alt = (int)r | (nt << 30);
+                            it.k_fw = fw[nt]; it.d_fw = d_fw; it.k_bw = bw[nt]; it.d_bw = d_bw;
+                            it.e_fw = te[0][nt]; it.e_bw = te[1][nt];
                             queue[(size_t)shard * queue_per_shard + i] = it;
                         } else {
                             atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
@@ -1256,11 +1258,9 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
 
 __global__ __launch_bounds__(256) void poisson_drain_kernel(
     const PcItem *__restrict__ queue, const long long queue_per_shard, const unsigned long long *__restrict__ queue_n,
-    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
-    const float *__restrict__ thr, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls,
-    const long long capacity, unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n)
+    const long long R, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls, const long long capacity,
+    unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n)
 {
-    const long long R = P + E;
     // the counter array of the NEXT poisson_call (the other half of a double buffer; its last reader, the previous
     // drain, finished before this kernel started) is reset here, which saves a memset launch per call
     if (blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) next_queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
@@ -1296,29 +1296,27 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
                 for (int step = AMPLI_CALL_SHARDS / 2; step > 0; step >>= 1)
                     if (cum[shard + step] <= g) shard += step;
                 it = queue[(size_t)shard * queue_per_shard + (g - cum[shard])];
-                const long long p = it.record < P ? it.record : (long long)ext_pos[it.record - P];
-                const float err = thr[(strand * 4 + it.alt_pad) * P + p];
-                qv = ampli_poisson_score(strand ? it.k_bw : it.k_fw, strand ? it.d_bw : it.d_fw, err); // VC:895-896
+                const float err = strand ? it.e_bw : it.e_fw;
+                // err_eff = +inf stands for err == -1 (Q = -888, VC:3844-3849); 0 was already replaced by 0.0010008f
+                qv = isinf(err) ? -888.0 : ampli_poisson_score(strand ? it.k_bw : it.k_fw, strand ? it.d_bw : it.d_fw, err); // VC:895-896
             }
             const double q_other = __shfl_xor(qv, 1);
             if (on && strand == 0 && qv >= 5 && q_other >= 5) { // VC:898 (coverage was checked before queueing)
-                const size_t o = (size_t)it.sample * R + it.record;
-                atomicOr(&mask_words[o >> 2], (1u << it.alt_pad) << ((o & 3) * 8));
+                const int record = it.record_alt & 0x3FFFFFFF, alt = (it.record_alt >> 30) & 3;
+                const size_t o = (size_t)it.sample * R + record;
+                atomicOr(&mask_words[o >> 2], (1u << alt) << ((o & 3) * 8));
                 if (n_calls) {
                     const unsigned cs = (unsigned)(blockIdx.x % AMPLI_CALL_SHARDS);
                     const long long per = capacity / AMPLI_CALL_SHARDS;
                     const unsigned long long i = atomicAdd(&n_calls[cs * AMPLI_CALL_COUNTER_STRIDE], 1ull);
                     if (calls && (long long)i < per) {
-                        const int4 a0 = recs[o * 2], a1 = recs[o * 2 + 1];
-                        const int fw[4] = {a0.x, a0.y, a0.z, a0.w}, bw[4] = {a1.x, a1.y, a1.z, a1.w};
-                        const int FW = fw[0] + fw[1] + fw[2] + fw[3], BW = bw[0] + bw[1] + bw[2] + bw[3];
-                        const int alt = it.alt_pad;
+                        const int FW = it.d_fw, BW = it.d_bw; // RD = FW + BW (include/amplisolve_hip.h)
                         ampli_call c;
-                        c.sample = it.sample; c.record = it.record; c.alt = alt; c.pad = 0;
+                        c.sample = it.sample; c.record = record; c.alt = alt; c.pad = 0;
                         c.q_fw = qv; c.q_bw = q_other;
-                        c.af = (float)(fw[alt] + bw[alt]) / (float)(FW + BW);   // VC:814-817
-                        c.af_fw = FW == 0 ? 0.0f : (float)fw[alt] / (float)FW;  // VC:785-790
-                        c.af_bw = BW == 0 ? 0.0f : (float)bw[alt] / (float)BW;  // VC:805-810
+                        c.af = (float)(it.k_fw + it.k_bw) / (float)(FW + BW);   // VC:814-817
+                        c.af_fw = FW == 0 ? 0.0f : (float)it.k_fw / (float)FW;  // VC:785-790
+                        c.af_bw = BW == 0 ? 0.0f : (float)it.k_bw / (float)BW;  // VC:805-810
                         c.pad2 = 0.0f;
                         calls[(size_t)cs * per + i] = c;
                     }
@@ -1715,8 +1713,7 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
             dstream = ctx->side;
         }
         hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, dstream, (const PcItem *)ctx->queue,
-                           per, qn, (const int4 *)d_trecs, (long long)P, (long long)E, d_ext_pos, d_thr,
-                           (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
+                           per, qn, (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
         if (ctx->async_drain) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_drain_done, ctx->side));
             ctx->drain_pending = true;
