@@ -243,8 +243,8 @@ int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_
  * queued survivors) is one fp64 scorer chain long and independent of what the caller enqueues next.  With
  * ampli_set_async_drain(ctx, 1) it runs on a side stream of the context: the call mask, the call list and
  * d_n_calls of a poisson_call are then complete only after ampli_wait_calls (the context's stream waits, the host
- * does not block), ampli_sync, ampli_copy_d2h, ampli_ctx_flags or the next ampli_poisson_call; d_thr, d_trecs and
- * the outputs must stay untouched until then. */
+ * does not block), ampli_sync, ampli_copy_d2h, ampli_ctx_flags or the next ampli_poisson_call; the outputs must
+ * stay untouched until then (the queued items carry their own thresholds and depths). */
 int ampli_set_async_drain(ampli_ctx *ctx, int32_t on);
 int ampli_wait_calls(ampli_ctx *ctx);
 
