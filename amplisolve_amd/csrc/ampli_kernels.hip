@@ -1643,6 +1643,7 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
     if (d_calls && (!d_n_calls || capacity < AMPLI_CALL_SHARDS)) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call list needs n_calls and capacity >= AMPLI_CALL_SHARDS");
     if (d_n_calls && !d_calls) capacity = 0;
     if (((uintptr_t)d_trecs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned");
+    if (P + E >= (1ll << 30)) return fail(ctx, AMPLI_E_RANGE, "poisson_call: P + E must be below 2^30 records per sample");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rcj = join_drain(ctx); if (rcj) return rcj; } // the queue, its counters and the call list are about to be reused
     const long long R = P + E;
