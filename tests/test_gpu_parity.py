@@ -596,3 +596,18 @@ def test_baseline_configs_4_and_5_full_size(ctx, name, P, S, T, depth):
     assert n == bits > 0
     del nor, tum, res, fin
     torch.cuda.empty_cache()
+
+
+def test_exactness_envelope_flag(ctx):
+    """With a tiny C and coverage cutoff 1 the fp32 products carry bits far below the running sums: the double
+    accumulation is then no longer exact (hence order dependent) and error_finalize must say so (flag bit 0) instead of
+    passing an order-dependent table on; the usual parameters keep the flag clear on the same records."""
+    P, S = 256, 24
+    recs = synth_recs(P, S)
+    d = _t(recs)
+    ok = ctx.error_estimate(d, P, 0.002, 100)
+    assert int(ok.flags.item()) == 0
+    bad = ctx.error_estimate(d, P, 1e-7, 1)
+    assert int(bad.flags.item()) & 1
+    two = ctx.error_finalize(ctx.error_reduce(d, P, 1e-7, 1), 1e-7, 1)
+    assert int(two.flags.item()) & 1
