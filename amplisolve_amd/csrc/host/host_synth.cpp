@@ -29,3 +29,7 @@ extern "C" void ampli_host_text_roundtrip_batch(const float *in, int64_t n, floa
 extern "C" int32_t ampli_host_af_limit(int32_t d) { return ampli_af_limit(d); }
 extern "C" int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err) { return ampli_prefilter_nocall(k, rd, err); }
 extern "C" int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err) { return ampli_prefilter_skip_f32(k, rd, ampli_effective_err(err)); }
+extern "C" void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = ampli_af_limit(d[i]);
+}

@@ -28,6 +28,7 @@ int ampli_host_synth_ref(uint8_t *ref_code /*[P]*/, int64_t P, uint64_t seed);
 /* ---- scalar helpers of csrc/ampli_math.h compiled for the host (formatting, unit checks) ---- */
 void ampli_host_text_roundtrip_batch(const float *in, int64_t n, float *out);
 int32_t ampli_host_af_limit(int32_t d);
+void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *out);
 int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err);
 int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err); /* the streaming kernel's fp32 form */
 

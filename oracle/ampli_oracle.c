@@ -136,6 +136,11 @@ int oracle_af_gate(int32_t x, int32_t d)
     return af <= 0.05;
 }
 
+void oracle_af_gate_batch(const int32_t *x, const int32_t *d, int64_t n, uint8_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)oracle_af_gate(x[i], d[i]);
+}
+
 static inline void visit_record(const int32_t *r, int32_t sample_index, float C, int32_t cov,
                                 int64_t p, int64_t P, double *snt, double *srd_d, int32_t *cnt,
                                 int32_t *nrec, int32_t *gm_n, int32_t *gm_first,

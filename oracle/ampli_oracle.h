@@ -93,6 +93,7 @@ void oracle_poisson_call(const int32_t *trecs, int64_t P, int64_t E, const uint3
 /* ---- integer AF-gate equivalence helper used by the product kernels ---- */
 /* 1 iff (double)((float)x/(float)d) <= 0.05, evaluated exactly like EE:1592-1595 */
 int oracle_af_gate(int32_t x, int32_t d);
+void oracle_af_gate_batch(const int32_t *x, const int32_t *d, int64_t n, uint8_t *out);
 
 #ifdef __cplusplus
 }

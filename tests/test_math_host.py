@@ -103,3 +103,19 @@ def test_fp32_prefilter_is_conservative():
     assert n_skip > 50000 and n_keep > 50000
     # and it is not vacuous: a count well below the mean is skipped, one above is kept
     assert H.ampli_host_prefilter_skip_f32(1, 1000, 0.002) == 1 and H.ampli_host_prefilter_skip_f32(3, 1000, 0.002) == 0
+
+
+def test_af_gate_integer_bound_exhaustive_over_all_depths():
+    """EVERY depth the integer gate is used for (1 <= d < 2^24): the bound is tight -- x = limit passes the
+    reference's fp32 test, x = limit + 1 fails it; the test is monotone in x, so this is the whole equivalence."""
+    H, O = host_lib(), orc.lib()
+    d = np.arange(1, 1 << 24, dtype=np.int32)
+    lim = np.empty_like(d)
+    H.ampli_host_af_limit_batch(d.ctypes.data_as(C.c_void_p), d.size, lim.ctypes.data_as(C.c_void_p))
+    out = np.empty(d.size, np.uint8)
+    O.oracle_af_gate_batch(lim.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_int64(d.size), out.ctypes.data_as(C.c_void_p))
+    assert out.all()
+    lim1 = lim + 1
+    O.oracle_af_gate_batch(lim1.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_int64(d.size), out.ctypes.data_as(C.c_void_p))
+    assert not out.any()
+    assert (np.abs(lim - 0.05 * d.astype(np.float64)) <= 1).all()
