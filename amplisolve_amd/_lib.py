@@ -58,6 +58,11 @@ HIP_SYMBOLS = {
     "ampli_error_estimate": (C.c_int, [vp, vp, i64, i64, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ampli_error_reduce_packed": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, C.POINTER(AccTable), vp]),
     "ampli_error_finalize_merged": (C.c_int, [vp, i64, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp]),
+    "ampli_slice_len": (i64, [i64, i32]),
+    "ampli_slice_bytes": (C.c_int, [i64, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "ampli_error_reduce_sliced": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "ampli_error_finalize_slice": (C.c_int, [vp, i64, i32, i32, vp, vp, f32, i32, vp]),
+    "ampli_error_table_unslice": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ampli_acc_merge": (C.c_int, [vp, C.POINTER(AccTable), C.POINTER(AccTable), i32]),
     "ampli_acc_packed_len": (i64, [i64]),
     "ampli_acc_pack": (C.c_int, [vp, C.POINTER(AccTable), vp]),

@@ -223,6 +223,29 @@ class Context:
                                                          _ptr(out.germ_present), _ptr(out.flags)))
         return out
 
+    # ---- position-sliced merge (reduce-scatter / all-to-all / all-gather; include/amplisolve_hip.h) ----
+    def slice_len(self, P: int, n_slices: int) -> int:
+        return int(self.lib.ampli_slice_len(P, n_slices))
+
+    def error_reduce_sliced(self, recs, P: int, n_slices: int, sums, gm, C_value: float = 0.002, cov: int = 100, E: int = 0,
+                            dup_off=None, first_sample: int = 0):
+        """Shard reduction straight into the exchange buffers: sums f64 [n][21][L], gm f32 [n][8][L]."""
+        S = recs.shape[0]
+        self._check(self.lib.ampli_error_reduce_sliced(self.h, _ptr(recs), P, E, _ptr(dup_off), S, first_sample, C_value, cov,
+                                                       n_slices, _ptr(sums), _ptr(gm)))
+
+    def error_finalize_slice(self, P: int, n_slices: int, slice_index: int, sum_slice, gm_recv, block, C_value: float = 0.002,
+                             cov: int = 100):
+        self._check(self.lib.ampli_error_finalize_slice(self.h, P, n_slices, slice_index, _ptr(sum_slice), _ptr(gm_recv),
+                                                        C_value, cov, _ptr(block)))
+
+    def error_table_unslice(self, P: int, n_slices: int, blocks, out: ErrorTable | None = None) -> ErrorTable:
+        if out is None:
+            out = self._new_error_table(P)
+        self._check(self.lib.ampli_error_table_unslice(self.h, P, n_slices, _ptr(blocks), _ptr(out.rate), _ptr(out.code),
+                                                       _ptr(out.thr), _ptr(out.germ_val), _ptr(out.germ_present), _ptr(out.flags)))
+        return out
+
     def acc_merge(self, parts: list[Acc], dst: Acc | None = None) -> Acc:
         if dst is None:
             dst = self.new_acc(parts[0].P)

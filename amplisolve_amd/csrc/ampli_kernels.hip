@@ -529,6 +529,10 @@ __device__ __forceinline__ void lane_acc_load(const AccPtrs &t, long long P, lon
 struct FinOut {
     float *rate; unsigned char *code; float *thr; float *germ_val; unsigned char *germ_present; int *flags;
     double *packed; // optional: the additive planes as [snt 8P | srd 8P | cnt 4P | nrec P] doubles (multi-GPU merge)
+    // position-sliced exchange buffers (reduce-scatter / all-to-all merge): slice k = positions [k*slice_len, (k+1)*slice_len)
+    long long slice_len; // 0: `packed` is plane-major over the whole panel (above)
+    double *sl_sums;     // [n_slices][21][slice_len]: the same 21 additive planes, slice-major
+    float *sl_gm;        // [n_slices][8][slice_len]: germ-max first_af[4] (-1 = no qualifying record) | rest[4]
 };
 
 __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, const long long P, const long long p, const LaneAcc &a)
@@ -542,6 +546,26 @@ __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, c
         pk[16 * P + nt * P + p] = (double)a.cnt[nt];
     }
     pk[20 * P + p] = (double)a.nrec;
+}
+
+// slice-major stores for the reduce-scatter merge: each destination rank's slice is one contiguous chunk
+__device__ __forceinline__ void lane_acc_store_sliced(const FinOut &o, const long long p, const LaneAcc &a)
+{
+    const long long L = o.slice_len, k = p / L, q = p - k * L;
+    double *__restrict__ pk = o.sl_sums + (size_t)k * 21 * L + q;
+    float *__restrict__ gm = o.sl_gm + (size_t)k * 8 * L + q;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        pk[(0 * 4 + nt) * L] = a.snt[0][nt];
+        pk[(1 * 4 + nt) * L] = a.snt[1][nt];
+        pk[(8 + 0 * 4 + nt) * L] = (double)a.srd[0][nt];
+        pk[(8 + 1 * 4 + nt) * L] = (double)a.srd[1][nt];
+        pk[(16 + nt) * L] = (double)a.cnt[nt];
+        // what the ordered fold needs of a shard: whether it has a qualifying record, its first AF, the max of the rest
+        gm[nt * L] = a.gm_n[nt] > 0 ? a.gm_first_af[nt] : -1.0f;
+        gm[(4 + nt) * L] = a.gm_n[nt] > 1 ? a.gm_rest[nt] : -INFINITY;
+    }
+    pk[20 * L] = (double)a.nrec;
 }
 
 // germ-max planes only (the additive planes travel in the packed buffer)
@@ -870,6 +894,8 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
                 } else {
                     lane_acc_store(t, P, p_raw, a);
                 }
+            } else if (fin.slice_len) { // multi-GPU shard, sliced exchange: no table at all
+                lane_acc_store_sliced(fin, p_raw, a);
             }
             // fused epilogue (single split only): the merged state is in registers, finalize it here and spare the
             // table round trip through HBM plus a launch
@@ -1018,6 +1044,92 @@ __global__ __launch_bounds__(256) void error_finalize_merged_kernel(const double
     }
     a.nrec = (int)pk[20 * P + p];
     finalize_lane(a, P, p, C, cov, o);
+}
+
+// ---------------------------------------------------------------------------
+// Position-sliced merge (reduce-scatter / all-to-all / all-gather): rank k owns positions [k*L, (k+1)*L).
+//   error_finalize_slice_kernel: the reduce-scattered sums of one slice + every rank's germ-max pair for that slice
+//                                (folded in rank order = sample order) -> one error-table block
+//   error_table_unslice_kernel : the all-gathered blocks -> the plane-major error table poisson_call reads
+// Block of a slice (all-gather unit): rate f32[8][L] | thr f32[8][L] | germ_val f32[4][L] | code u8[4][L] |
+// germ_present u8[4][L] | 64-byte tail (int32 flags).
+// ---------------------------------------------------------------------------
+__host__ __device__ __forceinline__ size_t slice_block_bytes(const long long L) { return (size_t)L * 88 + 64; }
+
+__device__ __forceinline__ FinOut slice_block_view(char *blk, const long long L)
+{
+    FinOut o = {};
+    o.rate = (float *)blk;
+    o.thr = (float *)(blk + (size_t)L * 32);
+    o.germ_val = (float *)(blk + (size_t)L * 64);
+    o.code = (unsigned char *)(blk + (size_t)L * 80);
+    o.germ_present = (unsigned char *)(blk + (size_t)L * 84);
+    o.flags = (int *)(blk + (size_t)L * 88);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double *__restrict__ sums, const float *__restrict__ gm,
+                                                                   const int nparts, const long long L, const long long p0,
+                                                                   const long long P, const float C, const int cov, char *blk)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= L || p0 + q >= P) return;
+    LaneAcc a;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        a.snt[0][nt] = sums[(0 * 4 + nt) * L + q];
+        a.snt[1][nt] = sums[(1 * 4 + nt) * L + q];
+        a.srd[0][nt] = (long long)sums[(8 + 0 * 4 + nt) * L + q];
+        a.srd[1][nt] = (long long)sums[(8 + 1 * 4 + nt) * L + q];
+        a.cnt[nt] = (int)sums[(16 + nt) * L + q];
+        int n = 0;
+        float rest = -INFINITY;
+        for (int k = 0; k < nparts; ++k) { // L (+) R = (L.first, max(L.rest, R.first_af, R.rest)), shards in sample order
+            const float fa = gm[((size_t)k * 8 + nt) * L + q];
+            if (fa < 0.0f) continue; // shard without a qualifying record
+            const float rr = gm[((size_t)k * 8 + 4 + nt) * L + q];
+            if (n == 0) { rest = rr; n = (rr > -INFINITY) ? 2 : 1; }
+            else { if (rest <= fa) rest = fa; if (rest <= rr) rest = rr; n = 2; }
+        }
+        a.gm_n[nt] = n; a.gm_rest[nt] = rest; a.gm_first[nt] = 0; a.gm_first_af[nt] = 0.0f; // n: 0, 1 or "more than one"
+    }
+    a.nrec = (int)sums[20 * L + q];
+    finalize_lane(a, L, q, C, cov, slice_block_view(blk, L));
+}
+
+__global__ __launch_bounds__(256) void error_table_unslice_kernel(const char *__restrict__ blocks, const int nparts, const long long L,
+                                                                  const long long P, const FinOut o)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0 && o.flags) {
+        int f = 0;
+        for (int k = 0; k < nparts; ++k) f |= *(const int *)(blocks + (size_t)k * slice_block_bytes(L) + (size_t)L * 88);
+        if (f) atomicOr(o.flags, f);
+    }
+    if (p >= P) return;
+    const long long k = p / L, q = p - k * L;
+    const FinOut b = slice_block_view(const_cast<char *>(blocks) + (size_t)k * slice_block_bytes(L), L);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        o.rate[j * P + p] = b.rate[j * L + q];
+        if (o.thr) o.thr[j * P + p] = b.thr[j * L + q];
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        o.code[nt * P + p] = b.code[nt * L + q];
+        if (o.germ_val) o.germ_val[nt * P + p] = b.germ_val[nt * L + q];
+        if (o.germ_present) o.germ_present[nt * P + p] = b.germ_present[nt * L + q];
+    }
+}
+
+// table -> slice-major exchange buffers (only when the sample axis had to be split across workgroups)
+__global__ __launch_bounds__(256) void acc_pack_sliced_kernel(AccPtrs t, const long long P, const FinOut o)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    LaneAcc a;
+    lane_acc_load(t, P, p, a);
+    lane_acc_store_sliced(o, p, a);
 }
 
 // Compact call list, sharded: a returning atomic on ONE word serialises at ~11 ns per add (about 90 per us chip-wide,
@@ -1415,7 +1527,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
                              const FinOut &fin)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate) || (fin.packed && !d_acc))
+    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate && !fin.slice_len) || (fin.packed && !d_acc))
         return fail(ctx, AMPLI_E_INVALID, "error_reduce: bad argument (P,S>0, cov>=1, table bound with ampli_acc_bind for the same P)");
     if (E > 0 && !d_dup_off) return fail(ctx, AMPLI_E_INVALID, "error_reduce: E > 0 needs dup_off");
     if (((uintptr_t)d_recs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned");
@@ -1461,6 +1573,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         stride = off[8];
         kfin.rate = nullptr;
         kfin.packed = nullptr; // packed after the merge, below
+        kfin.slice_len = 0;
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                                                                                       \
@@ -1490,6 +1603,15 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
             hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc),
                                (long long)P, fin.packed);
             rc = check_launch(ctx, "acc_pack_kernel");
+            if (rc) return rc;
+        }
+        if (fin.slice_len) {
+            AccPtrs t;
+            t.snt = (double *)(merged + off[0]); t.srd = (long long *)(merged + off[1]); t.cnt = (int *)(merged + off[2]);
+            t.nrec = (int *)(merged + off[3]); t.gm_n = (int *)(merged + off[4]); t.gm_first = (int *)(merged + off[5]);
+            t.gm_first_af = (float *)(merged + off[6]); t.gm_rest = (float *)(merged + off[7]);
+            hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, t, (long long)P, fin);
+            rc = check_launch(ctx, "acc_pack_sliced_kernel");
             if (rc) return rc;
         }
         if (fin.rate) {
@@ -1547,6 +1669,62 @@ extern "C" int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const doub
                        (const char *)d_gm_regions, off[5] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, (long long)P, C,
                        (int)cov, fo);
     return check_launch(ctx, "error_finalize_merged_kernel");
+}
+
+extern "C" int64_t ampli_slice_len(int64_t P, int32_t n_slices)
+{
+    if (P <= 0 || n_slices < 1) return 0;
+    const int64_t per = (P + n_slices - 1) / n_slices;
+    return (per + 63) / 64 * 64;
+}
+
+extern "C" int ampli_slice_bytes(int64_t P, int32_t n_slices, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes)
+{
+    const int64_t L = ampli_slice_len(P, n_slices);
+    if (L <= 0) return AMPLI_E_INVALID;
+    if (sums_bytes) *sums_bytes = (size_t)n_slices * 21 * (size_t)L * sizeof(double);
+    if (gm_bytes) *gm_bytes = (size_t)n_slices * 8 * (size_t)L * sizeof(float);
+    if (block_bytes) *block_bytes = slice_block_bytes(L);
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
+                                         int32_t S, int32_t first_sample, float C, int32_t cov, int32_t n_slices,
+                                         double *d_sums, float *d_gm)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_sums || !d_gm || n_slices < 1) return fail(ctx, AMPLI_E_INVALID, "error_reduce_sliced: exchange buffers and n_slices >= 1 are required");
+    FinOut fo = {};
+    fo.slice_len = ampli_slice_len(P, n_slices);
+    fo.sl_sums = d_sums;
+    fo.sl_gm = d_gm;
+    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, nullptr, fo);
+}
+
+extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_slices, int32_t slice_index,
+                                          const double *d_sum_slice, const float *d_gm_recv, float C, int32_t cov, void *d_block)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (P <= 0 || n_slices < 1 || slice_index < 0 || slice_index >= n_slices || !d_sum_slice || !d_gm_recv || !d_block || cov < 1)
+        return fail(ctx, AMPLI_E_INVALID, "error_finalize_slice: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long L = ampli_slice_len(P, n_slices);
+    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, d_sum_slice,
+                       d_gm_recv, (int)n_slices, L, (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block);
+    return check_launch(ctx, "error_finalize_slice_kernel");
+}
+
+extern "C" int ampli_error_table_unslice(ampli_ctx *ctx, int64_t P, int32_t n_slices, const void *d_blocks, float *d_rate,
+                                         uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present,
+                                         int32_t *d_flags)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (P <= 0 || n_slices < 1 || !d_blocks || !d_rate || !d_code) return fail(ctx, AMPLI_E_INVALID, "error_table_unslice: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
+    hipLaunchKernelGGL(error_table_unslice_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const char *)d_blocks, (int)n_slices, (long long)ampli_slice_len(P, n_slices), (long long)P, fo);
+    return check_launch(ctx, "error_table_unslice_kernel");
 }
 
 extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, const ampli_acc_table *d_parts, int32_t nparts)

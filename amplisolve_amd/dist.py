@@ -118,3 +118,78 @@ class TableMerger:
         w_g.wait()
         self.fold(acc, self.gathered[slot], self.world)
         return acc
+
+
+def slice_geometry(P: int, world: int):
+    """(L, sums_bytes, gm_bytes, block_bytes) of the position-sliced exchange (ampli_slice_len / ampli_slice_bytes)."""
+    from ._lib import hip_lib
+
+    lib = hip_lib()
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    if lib.ampli_slice_bytes(P, world, C.byref(a), C.byref(b), C.byref(c)) != 0:
+        raise ValueError("ampli_slice_bytes failed")
+    return int(lib.ampli_slice_len(P, world)), a.value, b.value, c.value
+
+
+class SlicedMerger:
+    """Position-sliced merge of the ranks' partial error statistics (include/amplisolve_hip.h, "Position-sliced merge").
+
+    Rank k owns the positions [k*L, (k+1)*L).  Per batch:
+
+        error_reduce_sliced -> sums[slot] f64 [world][21][L], gm[slot] f32 [world][8][L]
+        start_exchange(slot):  reduce-scatter(SUM) sums -> sum_slice[slot] [21][L]
+                               all-to-all gm           -> gm_recv[slot] [world][8][L]
+        error_finalize_slice   -> block[slot]          (this rank's slice of the error table)
+        start_gather(slot):    all-gather block        -> blocks[slot] [world][block_bytes]
+        error_table_unslice    -> the plane-major error table on every rank
+
+    Received bytes per rank and batch at world = 8, P = 100 k: 14.7 + 2.8 + 7.7 = 25 MB, against 29.4 + 33.6 = 63 MB
+    for the all-reduce + all-gather of whole tables (TableMerger).  `depth` buffer sets let a caller keep that many
+    batches in flight; the collectives ride on RCCL's stream.  Backends without reduce-scatter / all-to-all on device
+    tensors (gloo: rehearsals and CPU tests) get the same data movement out of all-reduce / all-gather.
+    """
+
+    def __init__(self, P: int, world: int, rank: int, device, group=None, depth: int = 3):
+        import torch
+        import torch.distributed as dist
+
+        self.P, self.world, self.rank, self.group, self.depth = P, world, rank, group, depth
+        self.L, sums_bytes, gm_bytes, self.block_bytes = slice_geometry(P, world)
+        L = self.L
+        self.native = dist.get_backend(group) == "nccl"
+        z = dict(device=device)
+        # zeroed once: entries of the padding positions (>= P) are never written by the kernels
+        self.sums = [torch.zeros(world * 21 * L, dtype=torch.float64, **z) for _ in range(depth)]
+        self.gm = [torch.zeros(world * 8 * L, dtype=torch.float32, **z) for _ in range(depth)]
+        self.sum_slice = [torch.zeros(21 * L, dtype=torch.float64, **z) for _ in range(depth)]
+        self.gm_recv = [torch.zeros(world * 8 * L, dtype=torch.float32, **z) for _ in range(depth)]
+        self.block = [torch.zeros(self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
+        self.blocks = [torch.zeros(world * self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
+        self._a2a_tmp = None if self.native else torch.zeros(world * world * 8 * L, dtype=torch.float32, **z)
+        assert sums_bytes == self.sums[0].numel() * 8 and gm_bytes == self.gm[0].numel() * 4
+
+    def start_exchange(self, slot: int):
+        import torch.distributed as dist
+
+        L, w, r = self.L, self.world, self.rank
+        if self.native:
+            h1 = dist.reduce_scatter_tensor(self.sum_slice[slot], self.sums[slot], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h2 = dist.all_to_all_single(self.gm_recv[slot], self.gm[slot], group=self.group, async_op=True)
+            return (h1, h2)
+        # rehearsal form: all-reduce + own chunk; all-gather + own column
+        dist.all_reduce(self.sums[slot], op=dist.ReduceOp.SUM, group=self.group)
+        self.sum_slice[slot].copy_(self.sums[slot][r * 21 * L:(r + 1) * 21 * L])
+        dist.all_gather_into_tensor(self._a2a_tmp, self.gm[slot], group=self.group)
+        self.gm_recv[slot].view(w, 8 * L).copy_(self._a2a_tmp.view(w, w, 8 * L)[:, r, :])
+        return ()
+
+    def start_gather(self, slot: int):
+        import torch.distributed as dist
+
+        return (dist.all_gather_into_tensor(self.blocks[slot], self.block[slot], group=self.group, async_op=True),)
+
+    @staticmethod
+    def wait(handle):
+        """The current stream waits for the collectives of `handle`."""
+        for h in handle:
+            h.wait()

@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1, help="N = 1 only: independent batches round-robin over this many HIP streams "
                     "(cross-batch overlap; per-kernel times then include contention, so the default stays 1)")
     ap.add_argument("--async-drain", action="store_true", help="poisson_call's drain kernel on a side stream (measured: no gain on config 3)")
+    ap.add_argument("--merge", default="sliced", choices=["sliced", "allreduce"],
+                    help="N>1 exchange: sliced = reduce-scatter + all-to-all + all-gather by position slices (default); "
+                         "allreduce = one packed all-reduce + all-gather of whole germ-max regions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
     return ap.parse_args()
@@ -202,7 +205,13 @@ def main():
 
     calls_buf = torch.empty((cap * ctypes.sizeof(Call),), dtype=torch.uint8, device=ctx.device)
     n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=ctx.device)
-    merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack) if world > 1 else None
+    from amplisolve_amd.dist import SlicedMerger
+
+    sliced = world > 1 and args.merge == "sliced"
+    merger = None
+    if world > 1:
+        merger = (SlicedMerger(P, world, rank, ctx.device) if sliced else
+                  TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack))
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
     ev_steps = [i for i in range(args.steps) if i % max(1, args.event_every) == 0]
@@ -220,6 +229,8 @@ def main():
             ctx.record(ev[i][0])
         if world == 1:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
             fins[i & 1] = fin = ctx.error_estimate(normals, P, 0.002, 100, out=fins[i & 1])
+        elif sliced:  # shard of a multi-GPU panel: sums and germ-max pairs straight into the slice-major exchange buffers
+            ctx.error_reduce_sliced(normals, P, world, merger.sums[slot], merger.gm[slot], 0.002, 100, first_sample=rank * S)
         else:  # shard of a multi-GPU panel: sums straight into the all-reduce buffer, gm planes into the table
             ctx.error_reduce_packed(normals, P, accs[slot], merger.packed[slot], 0.002, 100, first_sample=rank * S)
         if timed:
@@ -228,7 +239,9 @@ def main():
     def call_part(i, timed, slot):
         nonlocal fin
         timed = timed and i % max(1, args.event_every) == 0
-        if world > 1:  # finalize straight from the all-reduced sums + gathered germ-max regions
+        if sliced:  # the gathered blocks of every rank's slice -> the plane-major error table
+            fins[i & 1] = fin = ctx.error_table_unslice(P, world, merger.blocks[slot], out=fins[i & 1])
+        elif world > 1:  # finalize straight from the all-reduced sums + gathered germ-max regions
             fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
         if timed:
             ctx.record(ev[i][2])
@@ -247,6 +260,33 @@ def main():
             for i in range(n):
                 reduce_part(i, timed, 0)
                 call_part(i, timed, 0)
+            return
+        if sliced:
+            # three batches in flight: reduce(i) -> [reduce-scatter + all-to-all](i) | finalize_slice(i-1) -> [all-gather](i-1)
+            # | unslice + poisson_call(i-2); each collective has a whole error_reduce between its start and its wait
+            hx, hg = {}, {}
+
+            def mid(j):
+                sj = j % 3
+                merger.wait(hx.pop(j))
+                ctx.error_finalize_slice(P, world, rank, merger.sum_slice[sj], merger.gm_recv[sj], merger.block[sj], 0.002, 100)
+                hg[j] = merger.start_gather(sj)
+
+            def last(j):
+                merger.wait(hg.pop(j))
+                call_part(j, timed, j % 3)
+
+            for i in range(n):
+                reduce_part(i, timed, i % 3)
+                hx[i] = merger.start_exchange(i % 3)
+                if i >= 1:
+                    mid(i - 1)
+                if i >= 2:
+                    last(i - 2)
+            mid(n - 1)
+            if n >= 2:
+                last(n - 2)
+            last(n - 1)
             return
         pending = None
         for i in range(n):
@@ -296,8 +336,20 @@ def main():
                 if t:
                     c.record(ev[i][3])
 
-    run_steps(args.warmup, False)
-    fence()
+    try:
+        run_steps(args.warmup, False)
+        fence()
+    except Exception as exc:  # noqa: BLE001
+        # a runtime that rejects the sliced exchange's collectives does so on every rank at the first call:
+        # fall back, loudly, to the all-reduce form rather than lose the N > 1 measurement
+        if not sliced:
+            raise
+        print(f"rank {rank}: sliced merge failed in warm-up ({type(exc).__name__}: {exc}); falling back to --merge allreduce", file=sys.stderr)
+        sliced = False
+        args.merge = "allreduce"
+        merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack)
+        run_steps(args.warmup, False)
+        fence()
     if world > 1 and args.check:
         # every shard regenerated locally and reduced in one pass must equal the merged table, bit for bit
         allrecs = torch.cat([ctx.synth_fill(P, S, first_sample=k * S, seed=SEED, depth=depth) for k in range(world)])
@@ -356,7 +408,8 @@ def main():
         acc_bytes = ctx.lib.ampli_acc_bytes(P)
         # algorithmic bytes of error_reduce per launch: the records + what it writes (the accumulator table,
         # or at N = 1 the finalised error table: rate 32 B + thr 32 B + code 4 B + germ 16+4 B per position)
-        red_bytes = 32 * P * S + (acc_bytes if world > 1 else 88 * P)
+        # (N > 1, sliced merge: 21 doubles + 8 floats per position into the exchange buffers = 200 B)
+        red_bytes = 32 * P * S + ((200 * P if sliced else acc_bytes) if world > 1 else 88 * P)
         call_bytes = 32 * P * T + 33 * P + P * T           # poisson_call: records + thresholds/ref + mask
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = "error_reduce_kernel<true, 1>", t_red, red_bytes
@@ -391,7 +444,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "depth": depth,
                        "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if world == 1 else 1,
-                       "parallelism": f"tumour+normal sample shards x{world}" + ("; one packed RCCL all-reduce + all-gather of the error table per batch, overlapped with the neighbouring batches" if world > 1 else "")},
+                       "parallelism": f"tumour+normal sample shards x{world}" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table; three batches in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if world > 1 else ""),
+                       "merge": (args.merge if world > 1 else None)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
                          "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)" if traffic else None},

@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from amplisolve_amd.api import Acc
-from amplisolve_amd.dist import TableMerger, merge_error_table, shard_range, table_regions
+from amplisolve_amd.dist import SlicedMerger, TableMerger, merge_error_table, shard_range, slice_geometry, table_regions
 from oracle import pyoracle as orc
 from tests.helpers import synth_recs
 
@@ -88,6 +88,114 @@ def worker(rank, world, port, q):
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
+
+
+# ---- position-sliced merge: numpy twins of the three kernels around SlicedMerger's collectives ----
+def host_pack_sliced(part, P, world, L, sums, gm):
+    """twin of lane_acc_store_sliced (csrc/ampli_kernels.hip): partial table -> slice-major exchange buffers."""
+    planes = np.concatenate([part["snt"].reshape(8, P), part["srd"].reshape(8, P).astype(np.float64),
+                             part["cnt"].astype(np.float64), part["nrec"].reshape(1, P).astype(np.float64)])
+    pair = np.concatenate([np.where(part["gm_n"] > 0, part["gm_first_af"], np.float32(-1)),
+                           np.where(part["gm_n"] > 1, part["gm_rest"], np.float32(-np.inf))]).astype(np.float32)
+    s, g = sums.numpy().reshape(world, 21, L), gm.numpy().reshape(world, 8, L)
+    for k in range(world):
+        lo, hi = k * L, min(P, (k + 1) * L)
+        if hi > lo:
+            s[k, :, : hi - lo] = planes[:, lo:hi]
+            g[k, :, : hi - lo] = pair[:, lo:hi]
+
+
+def host_finalize_slice(sum_slice, gm_recv, world, L, n_valid):
+    """twin of error_finalize_slice_kernel: ordered fold of the shards' germ-max pairs + the oracle's finalize."""
+    s, g = sum_slice.numpy().reshape(21, L)[:, :n_valid], gm_recv.numpy().reshape(world, 8, L)[:, :, :n_valid]
+    n = np.zeros((4, n_valid), np.int32)
+    rest = np.full((4, n_valid), -np.inf, np.float32)
+    for k in range(world):
+        fa, rr = g[k, :4], g[k, 4:]
+        has = fa >= 0
+        first = has & (n == 0)
+        later = has & (n > 0)
+        rest[later] = np.maximum(rest[later], np.maximum(fa[later], rr[later]))
+        n[later] = 2
+        rest[first] = rr[first]
+        n[first] = np.where(rr[first] > -np.inf, 2, 1)
+    acc = dict(snt=np.ascontiguousarray(s[:8].reshape(2, 4, n_valid)), srd=np.ascontiguousarray(s[8:16].reshape(2, 4, n_valid).astype(np.int64)),
+               cnt=np.ascontiguousarray(s[16:20].astype(np.int32)), nrec=np.ascontiguousarray(s[20].astype(np.int32)),
+               gm_n=n, gm_rest=rest)
+    return orc.error_finalize(acc)
+
+
+def sliced_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L, _, _, block_bytes = slice_geometry(P, world)
+        merger = SlicedMerger(P, world, rank, "cpu")
+        lo, hi = shard_range(S, rank, world)
+        n_valid = max(0, min(P, (rank + 1) * L) - rank * L)
+        ok = True
+        batches = []
+        for b in range(3):  # three batches in flight, as bench.py keeps them
+            rb = synth_recs(P, S, seed=4321 + b)
+            host_pack_sliced(orc.error_reduce(rb[lo:hi], P, 0.002, 100, first_sample=lo), P, world, L, merger.sums[b], merger.gm[b])
+            batches.append((rb, merger.start_exchange(b)))
+        gathers = []
+        for b, (rb, h) in enumerate(batches):
+            merger.wait(h)
+            fin = host_finalize_slice(merger.sum_slice[b], merger.gm_recv[b], world, L, n_valid)
+            # block = this rank's slice of the table, serialised (here: rate | thr | code | germ_present | germ_val as f64)
+            blob = np.concatenate([fin["rate"].reshape(-1).view(np.uint8), fin["thr"].reshape(-1).view(np.uint8), fin["code"].reshape(-1),
+                                   fin["germ_present"].reshape(-1), fin["germ_val"].reshape(-1).view(np.uint8)])
+            assert blob.size <= block_bytes + 16 * L  # f64 germ values in the host twin; the device block carries f32
+            blk = torch.zeros(104 * L, dtype=torch.uint8)
+            blk[: blob.size] = torch.from_numpy(blob)
+            merger.block[b] = blk
+            merger.blocks[b] = torch.zeros(world * 104 * L, dtype=torch.uint8)
+            gathers.append((rb, merger.start_gather(b)))
+        for b, (rb, h) in enumerate(gathers):
+            merger.wait(h)
+            full = orc.error_finalize(orc.error_reduce(rb, P, 0.002, 100))
+            allb = merger.blocks[b].numpy().reshape(world, 104 * L)
+            for k in range(world):
+                nv = max(0, min(P, (k + 1) * L) - k * L)
+                if nv == 0:
+                    continue
+                sl = slice(k * L, k * L + nv)
+                o = 0
+                for name, shape, dt in (("rate", (2, 4, nv), np.float32), ("thr", (2, 4, nv), np.float32), ("code", (4, nv), np.uint8),
+                                        ("germ_present", (4, nv), np.uint8), ("germ_val", (4, nv), np.float64)):
+                    nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+                    got = allb[k, o:o + nb].view(dt).reshape(shape)
+                    o += nb
+                    exp = full[name][..., sl]
+                    if name == "germ_val":
+                        m = full["germ_present"][..., sl] > 0
+                        ok &= bool(np.array_equal(got[m], exp[m]))
+                    else:
+                        ok &= bool(np.array_equal(got.view(np.uint8), np.ascontiguousarray(exp).view(np.uint8)))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sliced_merge_protocol_over_gloo(world):
+    """Slice ownership, chunk order of the reduce-scatter / all-to-all / all-gather and the ordered germ-max fold:
+    every rank ends with every slice of the single-pass error table, bit for bit."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=sliced_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(r for r, _ in res) == list(range(world))
+    assert all(ok for _, ok in res)
 
 
 def test_shard_range_partitions():

@@ -1,6 +1,8 @@
 """N > 1 bench path rehearsed on ONE GPU: two ranks share cuda:0 and talk over gloo (RCCL needs one GPU per rank).
-Exercises exactly the code the driver runs at N = 2/4/8 -- shard generation, the pipelined TableMerger, the
-device-side germ-max fold -- and checks the merged table against a single-pass reduction of all shards."""
+Exercises the code the driver runs at N = 2/4/8 -- shard generation, the pipelined mergers (position-sliced =
+default, and the all-reduce form), the device-side slice finalize / germ-max fold -- and checks the merged table
+against a single-pass reduction of all shards.  (Over gloo the sliced merger gets its reduce-scatter / all-to-all
+from all-reduce / all-gather; the RCCL calls themselves only run on a multi-GPU node.)"""
 import json
 import os
 import subprocess
@@ -12,14 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2])
-def test_bench_multirank_path_on_one_gpu(world):
+@pytest.mark.parametrize("world,merge", [(2, "sliced"), (3, "sliced"), (2, "allreduce")])
+def test_bench_multirank_path_on_one_gpu(world, merge):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "3",
-           "--backend", "gloo", "--check", "--config", "c2"]
+           "--backend", "gloo", "--check", "--config", "c2", "--merge", merge]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "check: merged error table == single-pass error table" in r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
+    assert d["config"]["merge"] == merge

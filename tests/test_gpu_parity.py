@@ -181,6 +181,84 @@ def test_shard_merge_matches_single_pass(ctx):
     assert_acc_equal(dst, full, skip=("gm_first",))  # the sample index is not part of the exchanged region
 
 
+def _sliced_merge_emulated(ctx, shards, P, firsts, E=0, dup_off=None, C_value=0.002, cov=100):
+    """The position-sliced merge (SlicedMerger's data movement) with the collectives replaced by tensor ops."""
+    import torch
+
+    from amplisolve_amd.dist import slice_geometry
+
+    n = len(shards)
+    L, _, _, block_bytes = slice_geometry(P, n)
+    sums, gms = [], []
+    for recs, first in zip(shards, firsts):
+        s = torch.zeros(n * 21 * L, dtype=torch.float64, device="cuda")
+        g = torch.zeros(n * 8 * L, dtype=torch.float32, device="cuda")
+        ctx.error_reduce_sliced(recs, P, n, s, g, C_value, cov, E=E, dup_off=dup_off, first_sample=first)
+        sums.append(s)
+        gms.append(g)
+    total = torch.stack(sums).sum(0).view(n, 21 * L)                      # reduce-scatter: rank k keeps row k
+    blocks = torch.zeros(n * block_bytes, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        recv = torch.stack([g.view(n, 8 * L)[k] for g in gms]).contiguous()  # all-to-all: chunk j = rank j's pair for slice k
+        ctx.error_finalize_slice(P, n, k, total[k].contiguous(), recv, blocks[k * block_bytes:(k + 1) * block_bytes], C_value, cov)
+    return ctx.error_table_unslice(P, n, blocks)                         # all-gather: the blocks back to back
+
+
+@pytest.mark.parametrize("P,S,n", [(2000, 48, 2), (1000, 37, 3), (4097, 64, 8), (100, 16, 8), (15, 300, 2), (777, 130, 4)])
+def test_sliced_merge_matches_single_pass(ctx, P, S, n):
+    """Reduce-scatter / all-to-all / all-gather merge of n sample shards == one pass over all samples."""
+    from amplisolve_amd.dist import shard_range
+
+    recs = synth_recs(P, S)
+    cuts = [shard_range(S, r, n) for r in range(n)]
+    ref = orc.error_finalize(orc.error_reduce(recs, P))
+    shards = [_t(recs[a:b]) for a, b in cuts if b > a]
+    firsts = [a for a, b in cuts if b > a]
+    if len(shards) < n:  # fewer samples than ranks cannot happen with shard_range here, but keep the emulation honest
+        pytest.skip("empty shard")
+    fin = _sliced_merge_emulated(ctx, shards, P, firsts)
+    assert_final_equal(fin, ref)
+    assert int(fin.flags.item()) == 0
+    one = ctx.error_estimate(_t(recs), P)
+    for a, b in ((fin.rate, one.rate), (fin.thr, one.thr), (fin.code, one.code), (fin.germ_present, one.germ_present)):
+        assert bool((a == b).all()) or np.array_equal(a.cpu().numpy().view(np.uint8), b.cpu().numpy().view(np.uint8))
+
+
+def test_sliced_merge_edge_cases_and_extras(ctx):
+    """Edge-case records (absent cells, depth around the cutoff, AF around 5 %, quorum failures, NaN rates) with
+    positions listed more than once per file, sharded down to one sample per rank so that many shards have no
+    qualifying record for a position (the -1 marker of the exchange)."""
+    from amplisolve_amd.dist import shard_range
+
+    rng = np.random.default_rng(23)
+    P, S = 333, 9
+    mult = np.zeros(P, np.int64)
+    mult[rng.choice(P, 40, replace=False)] = 1
+    mult[rng.choice(P, 5, replace=False)] = 2
+    dup_off = np.concatenate([[0], np.cumsum(mult)]).astype(np.uint32)
+    E = int(dup_off[-1])
+    recs = edge_case_recs(P + E, S, rng)
+    ref = orc.error_finalize(orc.error_reduce(recs, P, 0.002, 100, E=E, dup_off=dup_off))
+    for n in (2, 3, S):
+        cuts = [shard_range(S, r, n) for r in range(n)]
+        for general in (False, True):
+            ctx.set_tuning(0, general=general)
+            fin = _sliced_merge_emulated(ctx, [_t(recs[a:b]) for a, b in cuts], P, [a for a, _ in cuts], E=E, dup_off=_t(dup_off))
+            ctx.set_tuning(0)
+            assert_final_equal(fin, ref)
+
+
+def test_sliced_merge_reports_the_exactness_flag(ctx):
+    """A slice whose double sums leave the exactness envelope raises flag bit 0 through the gathered blocks
+    (same construction as test_exactness_envelope_flag)."""
+    P, S = 256, 24
+    recs = synth_recs(P, S)
+    ok = _sliced_merge_emulated(ctx, [_t(recs[:12]), _t(recs[12:])], P, [0, 12])
+    assert int(ok.flags.item()) == 0
+    bad = _sliced_merge_emulated(ctx, [_t(recs[:12]), _t(recs[12:])], P, [0, 12], C_value=1e-7, cov=1)
+    assert int(bad.flags.item()) & 1
+
+
 def test_text_roundtrip_device(ctx):
     import torch
 
