@@ -86,6 +86,16 @@ HIP_SYMBOLS = {
     "ampli_wait_calls": (C.c_int, [vp]),
 }
 
+class HostShard(C.Structure):
+    """mirror of ampli_host_shard (include/amplisolve_host.h): one shard of a multi-process run + its collective hooks"""
+    EE_BUFFERS = C.CFUNCTYPE(C.c_int, vp, i64, C.POINTER(vp))
+    HOOK = C.CFUNCTYPE(C.c_int, vp)
+    OR_FLAGS = C.CFUNCTYPE(C.c_int, vp, C.POINTER(i32))
+    ROWS_BEFORE = C.CFUNCTYPE(C.c_int, vp, i64, C.POINTER(i64))
+    _fields_ = [("index", i32), ("count", i32), ("user", vp), ("ee_buffers", EE_BUFFERS), ("ee_exchange", HOOK),
+                ("ee_gather", HOOK), ("or_flags", OR_FLAGS), ("rows_before", ROWS_BEFORE), ("barrier", HOOK)]
+
+
 HOST_SYMBOLS = {
     "ampli_host_synth_fill": (C.c_int, [vp, i64, i32, i32, u64, i32, i32]),
     "ampli_host_synth_ref": (C.c_int, [vp, i64, u64]),
@@ -115,6 +125,8 @@ HOST_SYMBOLS = {
     "ampli_host_read_error_table": (C.c_int, [C.c_char_p, C.POINTER(vp), vp, i64]),
     "ampli_host_run_error_estimation": (C.c_int, [C.c_char_p] * 8),
     "ampli_host_run_variant_calling": (C.c_int, [C.c_char_p] * 5),
+    "ampli_host_run_error_estimation_sharded": (C.c_int, [C.c_char_p] * 8 + [C.POINTER(HostShard)]),
+    "ampli_host_run_variant_calling_sharded": (C.c_int, [C.c_char_p] * 5 + [C.POINTER(HostShard)]),
     "ampli_host_fisher": (C.c_double, [C.c_int] * 4),
 }
 

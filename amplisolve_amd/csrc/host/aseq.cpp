@@ -5,6 +5,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -198,9 +199,17 @@ void parse_file(const Panel &panel, const std::string &path, bool keep_line, Fil
 } // namespace
 
 void cohort_load(const Panel &panel, const std::string &dir, const std::string &list_file, int n_threads, bool keep_line_no,
-                 bool print_irregular, Cohort &out)
+                 bool print_irregular, Cohort &out, int shard_index, int shard_count)
 {
     auto files = list_count_files(dir, list_file);
+    out.total_samples = (int)files.size();
+    out.first_sample = 0;
+    if (shard_count > 1) { // contiguous range of the visit order; earlier shards take the remainder (dist.py::shard_range)
+        const int n = (int)files.size(), base = n / shard_count, rem = n % shard_count;
+        const int lo = shard_index * base + std::min(shard_index, rem), hi = lo + base + (shard_index < rem ? 1 : 0);
+        files = decltype(files)(files.begin() + lo, files.begin() + hi);
+        out.first_sample = lo;
+    }
     const int S = (int)files.size();
     const int64_t P = panel.P();
     out.paths.clear(); out.names.clear();

@@ -50,6 +50,8 @@ static void load()
     BIND(dev_alloc, "ampli_dev_alloc") BIND(dev_free, "ampli_dev_free") BIND(copy_h2d, "ampli_copy_h2d")
     BIND(copy_d2h, "ampli_copy_d2h") BIND(memset_d, "ampli_memset_d") BIND(acc_bytes, "ampli_acc_bytes")
     BIND(acc_bind, "ampli_acc_bind") BIND(error_reduce, "ampli_error_reduce") BIND(error_finalize, "ampli_error_finalize") BIND(error_estimate, "ampli_error_estimate")
+    BIND(slice_len, "ampli_slice_len") BIND(slice_bytes, "ampli_slice_bytes") BIND(error_reduce_sliced, "ampli_error_reduce_sliced")
+    BIND(error_finalize_slice, "ampli_error_finalize_slice") BIND(error_table_unslice, "ampli_error_table_unslice")
     BIND(poisson_call, "ampli_poisson_call") BIND(set_tuning, "ampli_set_tuning") BIND(ctx_flags, "ampli_ctx_flags") BIND(set_queue_items, "ampli_set_queue_items")
 #undef BIND
     if (g_api.abi_version() != AMPLI_ABI_VERSION) { g_why = "libamplisolve_hip.so ABI version mismatch"; return; }

@@ -31,6 +31,12 @@ struct HipApi {
                           const ampli_acc_table *, float *, uint8_t *, float *, float *, uint8_t *, int32_t *);
     int (*error_finalize)(ampli_ctx *, const ampli_acc_table *, float, int32_t, float *, uint8_t *, float *, float *, uint8_t *,
                           int32_t *);
+    int64_t (*slice_len)(int64_t, int32_t);
+    int (*slice_bytes)(int64_t, int32_t, size_t *, size_t *, size_t *);
+    int (*error_reduce_sliced)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, int32_t, float, int32_t,
+                               int32_t, double *, float *);
+    int (*error_finalize_slice)(ampli_ctx *, int64_t, int32_t, int32_t, const double *, const float *, float, int32_t, void *);
+    int (*error_table_unslice)(ampli_ctx *, int64_t, int32_t, const void *, float *, uint8_t *, float *, float *, uint8_t *, int32_t *);
     int (*set_tuning)(ampli_ctx *, int32_t, int32_t);
     int (*ctx_flags)(ampli_ctx *, int32_t *, int32_t);
     int (*set_queue_items)(ampli_ctx *, int64_t);

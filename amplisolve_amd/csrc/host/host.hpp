@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../../include/amplisolve_hip.h"
+#include "../../../include/amplisolve_host.h"
 
 namespace ampli {
 
@@ -50,6 +51,7 @@ struct Cohort {
     std::vector<uint32_t> ext_pos;    // [E]
     std::vector<int32_t> line_no;     // [S][P+E] data-line index inside the sample's file, -1 absent
     int64_t n_lines = 0, n_offpanel = 0, n_irregular = 0, n_malformed = 0;
+    int first_sample = 0, total_samples = 0; // this cohort = samples [first_sample, first_sample + S()) of the directory's visit order
     ~Cohort();
     int S() const { return (int)paths.size(); }
     int64_t R() const { return P + E; }
@@ -67,8 +69,9 @@ void panel_load_fasta(Panel &p, const std::string &fasta_path);                 
 void panel_write_interm_files(const Panel &p, const std::string &dir, int seed);// EE:601, 657-664
 // ---- aseq.cpp ----
 std::vector<std::pair<std::string, std::string>> list_count_files(const std::string &dir, const std::string &list_file); // EE:552-559, 794-841
+// shard_index / shard_count: keep only that contiguous range of the visit order (multi-process runs)
 void cohort_load(const Panel &panel, const std::string &dir, const std::string &list_file, int n_threads, bool keep_line_no,
-                 bool print_irregular, Cohort &out);
+                 bool print_irregular, Cohort &out, int shard_index = 0, int shard_count = 1);
 // ---- table.cpp ----
 std::string format_rate_cell(uint8_t code, float r_fw, float r_bw, bool is_ref);  // EE:1704, 2670-2688
 std::string format_germ_cell(uint8_t present, float v);                           // EE:2807-2849
@@ -84,9 +87,11 @@ struct EeArgs {
     std::string panel_design, reference_genome, germline_dir, output_dir;
     std::string C_value = "0.002", coverage_cutoff = "100", default_error = "0.01";
     std::string refbases_file; // test hook: skip the FASTA, read chrom/pos/base lines
+    const ampli_host_shard *shard = nullptr; // one shard of a multi-process run (include/amplisolve_host.h)
 };
 struct VcArgs {
     std::string error_file, tumour_dir, output_dir, coverage_cutoff = "100", p_value = "0.05";
+    const ampli_host_shard *shard = nullptr;
 };
 int run_error_estimation(const EeArgs &a);
 int run_variant_calling(const VcArgs &a);

@@ -124,6 +124,35 @@ extern "C" int ampli_host_run_variant_calling(const char *error_file, const char
     return run_variant_calling(a);
 }
 
+static bool shard_ok(const ampli_host_shard *sh)
+{
+    return sh && sh->count >= 1 && sh->index >= 0 && sh->index < sh->count &&
+           (sh->count == 1 || (sh->ee_buffers && sh->ee_exchange && sh->ee_gather && sh->or_flags && sh->rows_before && sh->barrier));
+}
+
+extern "C" int ampli_host_run_error_estimation_sharded(const char *panel_design, const char *reference_genome, const char *germline_dir,
+                                                       const char *C_value, const char *coverage_cutoff, const char *default_error,
+                                                       const char *output_dir, const char *refbases_file, const ampli_host_shard *shard)
+{
+    if (!shard_ok(shard)) { g_err = "bad shard description"; return AMPLI_E_INVALID; }
+    EeArgs a;
+    a.panel_design = panel_design; a.reference_genome = reference_genome ? reference_genome : ""; a.germline_dir = germline_dir;
+    a.C_value = C_value; a.coverage_cutoff = coverage_cutoff; a.default_error = default_error; a.output_dir = output_dir;
+    if (refbases_file) a.refbases_file = refbases_file;
+    a.shard = shard;
+    return run_error_estimation(a);
+}
+
+extern "C" int ampli_host_run_variant_calling_sharded(const char *error_file, const char *tumour_dir, const char *output_dir,
+                                                      const char *coverage_cutoff, const char *p_value, const ampli_host_shard *shard)
+{
+    if (!shard_ok(shard)) { g_err = "bad shard description"; return AMPLI_E_INVALID; }
+    VcArgs a;
+    a.error_file = error_file; a.tumour_dir = tumour_dir; a.output_dir = output_dir; a.coverage_cutoff = coverage_cutoff; a.p_value = p_value;
+    a.shard = shard;
+    return run_variant_calling(a);
+}
+
 extern "C" double ampli_host_fisher(int a, int b, int c, int d) { return fisher_two_sided(a, b, c, d); }
 
 extern "C" int ampli_host_sample_order(const char *dir, char *out, int64_t cap)

@@ -124,8 +124,11 @@ int run_error_estimation(const EeArgs &a)
         }
         std::cout << "\t6. Output dir                                     : " << a.output_dir << std::endl;
 
+        const ampli_host_shard *sh = (a.shard && a.shard->count > 1) ? a.shard : nullptr;
+        const bool writer = !sh || sh->index == 0; // shard 0 writes every file of a multi-process run
+        auto hook = [&](int rc, const char *what) { if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what}; };
         const std::string interm = a.output_dir + "/AmpliSolveErrorEstimation_interm_files"; // EE:414
-        mkdir_p(interm);
+        if (writer) mkdir_p(interm);
         srand((unsigned)time(nullptr));
         const int seed = rand() % 1000; // EE:581-584
 
@@ -134,7 +137,7 @@ int run_error_estimation(const EeArgs &a)
         panel_from_bed(a.panel_design, panel);
         if (!a.refbases_file.empty()) panel_load_refbases_file(panel, a.refbases_file);
         else panel_load_fasta(panel, a.reference_genome);
-        panel_write_interm_files(panel, interm, seed);
+        if (writer) panel_write_interm_files(panel, interm, seed);
         std::cout << "\nRunning function generateReferenceBases: Reference bases and amplicon duplicated positions have generated"
                   << "\n\t\t --> Parsed in total " << panel.rows.size() << " amplicons and annotated " << panel.walk.size() << " positions." << std::endl;
         std::cout << "Running function storeReference: panel reference bases stored with success " << panel.P() << std::endl;
@@ -144,7 +147,7 @@ int run_error_estimation(const EeArgs &a)
 
         if (no_germlines) { // EE:472-506
             const std::string out = a.output_dir + "/positionSpecificNoise_default.txt";
-            write_error_table_default(panel, default_error, out);
+            if (writer) write_error_table_default(panel, default_error, out);
             std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
             std::cout << "\n" << kLine << std::endl;
             return 0;
@@ -155,8 +158,9 @@ int run_error_estimation(const EeArgs &a)
         const std::string list_name = interm + "/" + std::to_string(seed) + "_germline_count_list_original.txt"; // EE:442
         int threads = 0;
         if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
-        cohort_load(panel, a.germline_dir, list_name, threads, false, true, co);
-        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.S() << " samples" << std::endl;
+        cohort_load(panel, a.germline_dir, writer ? list_name : std::string(), threads, false, true, co, sh ? sh->index : 0, sh ? sh->count : 1);
+        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.total_samples << " samples" << std::endl;
+        if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << co.first_sample + 1 << ".." << co.first_sample + co.S() << std::endl;
         double t2 = now_s();
         std::cout << "Running function storeGermlineStatistics:" << std::endl;
 
@@ -170,6 +174,41 @@ int run_error_estimation(const EeArgs &a)
         int32_t *d_flags = dev.alloc<int32_t>(1);
         dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
         std::cout << "Running function estimateThresholds: ";
+        if (sh) {
+            // multi-process run: this shard's sums and germ-max pairs -> position-sliced exchange -> finalize of the own
+            // slice -> all-gather -> plane-major table on every shard (include/amplisolve_hip.h, "Position-sliced merge")
+            const int n = sh->count;
+            const int64_t L = dev.api->slice_len(P, n);
+            void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            hook(sh->ee_buffers(sh->user, P, bufs), "ee_buffers");
+            for (void *b : bufs)
+                if (!b) throw Error{AMPLI_E_INVALID, "shard hook ee_buffers returned a null buffer"};
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                if (co.S() > 0) {
+                    dev.check(dev.api->error_reduce_sliced(dev.ctx, d_recs, P, co.E, d_dup, co.S(), co.first_sample, C_value, cov, n,
+                                                           (double *)bufs[0], (float *)bufs[1]), "ampli_error_reduce_sliced");
+                } else { // a shard without samples: zero sums, "no qualifying record" germ-max pairs
+                    std::vector<float> none((size_t)n * 8 * L);
+                    for (int k = 0; k < n; ++k)
+                        for (int j = 0; j < 8; ++j)
+                            std::fill_n(none.begin() + ((size_t)k * 8 + j) * L, (size_t)L, j < 4 ? -1.0f : -INFINITY);
+                    dev.check(dev.api->memset_d(dev.ctx, bufs[0], 0, (size_t)n * 21 * L * sizeof(double)), "memset");
+                    dev.check(dev.api->copy_h2d(dev.ctx, bufs[1], none.data(), none.size() * sizeof(float)), "ampli_copy_h2d");
+                    dev.sync();
+                }
+                int32_t kflags = 0;
+                dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+                hook(sh->or_flags(sh->user, &kflags), "or_flags");
+                if (!(kflags & AMPLI_FLAG_RERUN_GENERAL) || attempt == 1) break;
+                dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning"); // some shard met a depth beyond the fast kernel: all rerun
+            }
+            hook(sh->ee_exchange(sh->user), "ee_exchange");
+            dev.check(dev.api->error_finalize_slice(dev.ctx, P, n, sh->index, (const double *)bufs[2], (const float *)bufs[3], C_value, cov,
+                                                    bufs[4]), "ampli_error_finalize_slice");
+            hook(sh->ee_gather(sh->user), "ee_gather");
+            dev.check(dev.api->error_table_unslice(dev.ctx, P, n, bufs[5], d_rate, d_code, nullptr, d_germ, d_gp, d_flags),
+                      "ampli_error_table_unslice");
+        } else {
         // reduce + finalize fused (the whole panel is on this device)
         dev.check(dev.api->error_estimate(dev.ctx, d_recs, P, co.E, d_dup, co.S(), C_value, cov, nullptr, d_rate, d_code, nullptr, d_germ,
                                           d_gp, d_flags), "ampli_error_estimate");
@@ -180,6 +219,7 @@ int run_error_estimation(const EeArgs &a)
             dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
             dev.check(dev.api->error_estimate(dev.ctx, d_recs, P, co.E, d_dup, co.S(), C_value, cov, nullptr, d_rate, d_code, nullptr,
                                               d_germ, d_gp, d_flags), "ampli_error_estimate");
+        }
         }
         std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
         std::vector<uint8_t> code((size_t)P * 4), gp((size_t)P * 4);
@@ -196,7 +236,8 @@ int run_error_estimation(const EeArgs &a)
         char name[64];
         snprintf(name, sizeof name, "positionSpecificNoise_%.4f.txt", (double)C_value); // EE:2556
         const std::string out = a.output_dir + "/" + name;
-        write_error_table(panel, rate.data(), code.data(), germ.data(), gp.data(), out);
+        if (writer) write_error_table(panel, rate.data(), code.data(), germ.data(), gp.data(), out);
+        if (sh) hook(sh->barrier(sh->user), "barrier");
         double t4 = now_s();
         std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
         if (getenv("AMPLISOLVE_TIMING"))
@@ -250,11 +291,14 @@ int run_variant_calling(const VcArgs &a)
         }
         std::cout << std::endl;
 
+        const ampli_host_shard *sh = (a.shard && a.shard->count > 1) ? a.shard : nullptr;
+        const bool writer = !sh || sh->index == 0; // shard 0 writes the shared files of a multi-process run
+        auto hook = [&](int rc, const char *what) { if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what}; };
         const std::string interm = a.output_dir + "/AmpliSolveVariantCalling_interm_files"; // VC:307
-        mkdir_p(interm);
+        mkdir_p(writer ? interm : a.output_dir);
         Panel panel;
         std::vector<float> thr;
-        panel_from_error_table(a.error_file, interm + "/dummyVCF_1.vcf", panel, thr); // VC:320
+        panel_from_error_table(a.error_file, writer ? interm + "/dummyVCF_1.vcf" : std::string(), panel, thr); // VC:320
         std::cout << "Running function storeInputFile: the error levels have stored with success " << panel.walk.size() << std::endl;
         srand((unsigned)time(nullptr));
         const int seed = rand() % 1000;
@@ -262,14 +306,15 @@ int run_variant_calling(const VcArgs &a)
         Cohort co;
         int threads = 0;
         if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
-        cohort_load(panel, a.tumour_dir, list_name, threads, true, true, co);
-        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.S() << " samples" << std::endl;
+        cohort_load(panel, a.tumour_dir, writer ? list_name : std::string(), threads, true, true, co, sh ? sh->index : 0, sh ? sh->count : 1);
+        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.total_samples << " samples" << std::endl;
+        if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << co.first_sample + 1 << ".." << co.first_sample + co.S() << std::endl;
         std::cout << "\nRunning function callVariants...." << std::endl;
 
         const int64_t P = co.P, R = co.R();
         const int T = co.S();
         std::vector<CallRow> rows;
-        {
+        if (T > 0 || !sh) { // a shard of a multi-process run may hold no tumour file
             Dev dev;
             dev.open();
             int32_t *d_recs = dev.upload(co.recs, (size_t)T * R * 8);
@@ -317,7 +362,14 @@ int run_variant_calling(const VcArgs &a)
         });
 
         const std::string summary = a.output_dir + "/Summary_Variant_Info.txt"; // VC:342
-        std::ofstream output(summary);
+        // multi-process run: every shard writes its rows to a part file; shard 0 concatenates them in shard order, which is
+        // the visit order.  VC:1066 switches the stream to 4 significant digits inside the first row EVER written, so a
+        // shard that is not the first to emit starts in that state.
+        int64_t before = 0;
+        if (sh) hook(sh->rows_before(sh->user, (int64_t)rows.size(), &before), "rows_before");
+        std::ofstream output(sh ? summary + ".part" + std::to_string(sh->index) : summary);
+        if (before > 0) output << std::setprecision(4);
+        if (writer)
         output << "Filename\tChrom\tPosition\tSubtitution\tRD\tRD_fw\tRD_bw\tAF\tReads_fw\tReads_bw\tAF_fw\tAF_bw\tAmpliconEdge_StrandBias\tFisherPvalue\tQscore_fw\tQscore_bw\tReadTier\tGermlineInfo\tMaxGermlineAF\t10merDownstream\t10merUpstream\tHomopolymerFlag" << std::endl; // VC:669
         size_t ri = 0;
         for (int t = 0; t < T; ++t) {
@@ -378,6 +430,20 @@ int run_variant_calling(const VcArgs &a)
             }
         }
         output.close();
+        if (sh) {
+            hook(sh->barrier(sh->user), "barrier");
+            if (writer) {
+                std::ofstream all(summary, std::ios::binary);
+                for (int k = 0; k < sh->count; ++k) {
+                    const std::string part = summary + ".part" + std::to_string(k);
+                    std::ifstream in(part, std::ios::binary);
+                    if (!in) throw Error{AMPLI_E_INVALID, "missing Summary part of shard " + std::to_string(k) + " (is output_dir shared by all processes?)"};
+                    all << in.rdbuf();
+                    in.close();
+                    std::remove(part.c_str());
+                }
+            }
+        }
         std::cout << "\nAmpliSolveVariantCalling execution was successful. The results can be found at : " << summary << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;

@@ -69,6 +69,34 @@ int ampli_host_run_error_estimation(const char *panel_design, const char *refere
 int ampli_host_run_variant_calling(const char *error_file, const char *tumour_dir, const char *output_dir,
                                    const char *coverage_cutoff, const char *p_value);
 
+/* ---- the same command lines as one shard of a multi-process (one process per GPU) run ----
+ * Samples shard by contiguous ranges of the visit order (shard k of n takes what amplisolve_amd/dist.py::shard_range
+ * gives it); every collective step is a callback, so the transport (torch.distributed over RCCL in
+ * amplisolve_amd/multi.py; gloo in the tests) stays outside this library.  Device work is enqueued on the device's
+ * default stream and the callbacks must be ordered with it.  Results are byte-identical to the one-process run.
+ *   error estimation: position-sliced merge of include/amplisolve_hip.h -- ee_buffers is called once P is known and
+ *   returns six DEVICE buffers sized by ampli_slice_bytes(P, count): [0] sums (zeroed), [1] gm, [2] sum_slice,
+ *   [3] gm_recv, [4] block (zeroed), [5] blocks; ee_exchange = reduce-scatter SUM [0]->[2] + all-to-all [1]->[3];
+ *   ee_gather = all-gather [4]->[5]; or_flags = bitwise OR of a host int over the shards.  Shard 0 writes the files.
+ *   variant calling: tumour files are independent; rows_before = exclusive prefix sum of the emitted rows (the
+ *   reference's Summary stream changes its float precision after the first row ever written, VC:1066); barrier; shard 0
+ *   then assembles Summary_Variant_Info.txt from the shards' parts. */
+typedef struct ampli_host_shard {
+    int32_t index, count;
+    void *user;
+    int (*ee_buffers)(void *user, int64_t P, void **d_bufs /*[6]*/);
+    int (*ee_exchange)(void *user);
+    int (*ee_gather)(void *user);
+    int (*or_flags)(void *user, int32_t *flags);
+    int (*rows_before)(void *user, int64_t mine, int64_t *before);
+    int (*barrier)(void *user);
+} ampli_host_shard;
+int ampli_host_run_error_estimation_sharded(const char *panel_design, const char *reference_genome, const char *germline_dir,
+                                            const char *C_value, const char *coverage_cutoff, const char *default_error,
+                                            const char *output_dir, const char *refbases_file, const ampli_host_shard *shard);
+int ampli_host_run_variant_calling_sharded(const char *error_file, const char *tumour_dir, const char *output_dir,
+                                           const char *coverage_cutoff, const char *p_value, const ampli_host_shard *shard);
+
 /* two-sided Fisher exact test of the post-call annotation (VC:3797-3814; own pmf, parity unpinned vs Boost) */
 double ampli_host_fisher(int a, int b, int c, int d);
 

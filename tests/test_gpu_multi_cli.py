@@ -1,0 +1,87 @@
+"""The one-process-per-GPU front end (amplisolve_amd/multi.py) against the one-process executables: same tokens, same
+files, byte for byte.  Rehearsed on ONE GPU: the ranks share cuda:0 and talk over gloo (RCCL needs a GPU per rank)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "amplisolve_amd", "bin")
+G = "/root/repo/tests/golden"  # the goldens were taken with this directory literal (it decides the visit order, EE:794-841)
+
+
+def torchrun(world, port, args, env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "amplisolve_amd.multi"] + args
+    e = dict(os.environ, AMPLISOLVE_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **(env or {}))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=e)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r
+
+
+def strip_dates(text):
+    return "\n".join(l for l in text.splitlines() if not l.startswith("##fileDate="))
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_error_estimation_sharded_equals_one_process(tmp_path, world):
+    """5 normal files over 2, 3 and 5 processes (the GPU box allows 6 processes on its card, pytest included)."""
+    d = f"{G}/toy_subset"
+    out = tmp_path / "multi"
+    torchrun(world, 29541 + world, ["AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
+                                    "C_value=0.002", "coverage_cutoff=100", "default_error=0.01", f"output_dir={out}"],
+             env={"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"})
+    assert (out / "positionSpecificNoise_0.0020.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0020.txt").read()
+    names = os.listdir(out / "AmpliSolveErrorEstimation_interm_files")
+    assert any(n.endswith("_germline_count_list_original.txt") for n in names) and any(n.endswith("_panelReferenceBases.txt") for n in names)
+
+
+def test_error_estimation_more_processes_than_files(tmp_path):
+    """2 normal files over 4 processes: two shards hold no file and contribute "no qualifying record" to the merge."""
+    d = f"{G}/toy_subset"
+    nd = tmp_path / "N2"
+    nd.mkdir()
+    for n in sorted(os.listdir(f"{d}/NORMAL"))[:2]:
+        os.symlink(f"{d}/NORMAL/{n}", nd / n)
+    args = [f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={nd}", "C_value=0.002", "coverage_cutoff=100",
+            "default_error=0.01"]
+    env = {"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"}
+    one, out = tmp_path / "one", tmp_path / "multi"
+    r = subprocess.run([f"{BIN}/AmpliSolveErrorEstimation"] + args + [f"output_dir={one}"], capture_output=True, text=True,
+                       env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1", **env))
+    assert r.returncode == 0, r.stdout + r.stderr
+    torchrun(4, 29549, ["AmpliSolveErrorEstimation"] + args + [f"output_dir={out}"], env=env)
+    assert (out / "positionSpecificNoise_0.0020.txt").read_text() == (one / "positionSpecificNoise_0.0020.txt").read_text()
+
+
+def test_error_estimation_sharded_edge_cases(tmp_path):
+    """The synthetic edge-case panel (positions listed twice, absent records, NaN rates, quorum failures) at cov 1."""
+    d = f"{G}/mini_edge"
+    out = tmp_path / "multi"
+    torchrun(3, 29551, ["AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
+                        "C_value=0.0005", "coverage_cutoff=1", "default_error=0.01", f"output_dir={out}"],
+             env={"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"})
+    assert (out / "positionSpecificNoise_0.0005.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0005_cov1.txt").read()
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_variant_calling_sharded_equals_one_process(tmp_path, world):
+    """3 tumour files (one without any call) over 2, 3 and 5 processes: Summary and every VCF as the one-process run."""
+    d = f"{G}/toy_subset"
+    table = f"{d}/expected_positionSpecificNoise_0.0020.txt"
+    one = tmp_path / "one"
+    r = subprocess.run([f"{BIN}/AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={d}/TUMOUR", f"output_dir={one}",
+                        "coverage_cutoff=100", "p_value=0.05"], capture_output=True, text=True, env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = tmp_path / "multi"
+    torchrun(world, 29561 + world, ["AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={d}/TUMOUR", f"output_dir={out}",
+                                    "coverage_cutoff=100", "p_value=0.05"])
+    assert (out / "Summary_Variant_Info.txt").read_text() == (one / "Summary_Variant_Info.txt").read_text()
+    vcfs = sorted(n for n in os.listdir(one) if n.endswith(".vcf"))
+    assert vcfs == sorted(n for n in os.listdir(out) if n.endswith(".vcf")) and len(vcfs) == 3
+    for n in vcfs:
+        assert strip_dates((out / n).read_text()) == strip_dates((one / n).read_text())
+    assert not [n for n in os.listdir(out) if ".part" in n]
+    assert os.path.exists(out / "AmpliSolveVariantCalling_interm_files" / "dummyVCF_1.vcf")

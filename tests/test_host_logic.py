@@ -128,3 +128,14 @@ def test_fisher_matches_scipy():
         want = scipy.fisher_exact([[a, c], [b, d]])[1]
         assert got == pytest.approx(want, rel=1e-6, abs=1e-12)
     assert H.ampli_host_fisher(461, 536, 196, 223) == pytest.approx(0.861148, abs=5e-7)  # SURVEY App. D, first Toy_data call
+
+
+def test_multi_front_end_token_parsing_and_usage(capsys):
+    """amplisolve_amd/multi.py reads its tokens like the reference's mains (sscanf "key=%s", EE:300-326 / VC:242-260)."""
+    from amplisolve_amd import multi
+
+    assert multi._token("panel_design=/a/b.bed", "panel_design") == "/a/b.bed"
+    assert multi._token("C_value=0.002 trailing", "C_value") == "0.002"
+    assert multi._token("coverage=100", "coverage_cutoff") == "" and multi._token("p_value=", "p_value") == ""
+    assert multi.main(["multi", "AmpliSolveVariantCalling", "errorFile=x"]) == 1  # wrong token count: usage, no GPU touched
+    assert "usage" in capsys.readouterr().out
