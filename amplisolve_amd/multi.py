@@ -128,28 +128,45 @@ def main(argv=None) -> int:
     dev = local % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     os.environ["AMPLISOLVE_DEVICE"] = str(dev)  # the C++ host opens its context on this device's default stream
+    quiet = None
     if rank != 0 and not os.environ.get("AMPLISOLVE_ALL_RANKS_VERBOSE"):
-        # the C++ pipeline narrates on stdout like the reference; one narrator is enough
+        # the C++ pipeline narrates on stdout like the reference; one narrator is enough -- the others' text is kept
+        # in an unnamed file and shown only if that shard fails
+        import tempfile
+
+        quiet = tempfile.TemporaryFile()
         sys.stdout.flush()
-        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+        os.dup2(quiet.fileno(), 1)
     backend = os.environ.get("AMPLISOLVE_DIST_BACKEND", "nccl")
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group(backend)
+    hooks = Hooks(rank, world, torch.device("cuda", dev))
+    lib = host_lib()
     try:
-        hooks = Hooks(rank, world, torch.device("cuda", dev))
-        lib = host_lib()
         if entry.startswith("ampli_host_run_error"):
             ref = os.environ.get("AMPLISOLVE_REFBASES_FILE")
             rc = getattr(lib, entry)(*toks, ref.encode() if ref else None, C.byref(hooks.struct))
         else:
             rc = getattr(lib, entry)(*toks, C.byref(hooks.struct))
-        if hooks.error:
-            print(hooks.error, file=sys.stderr)
-        return 0 if rc == 0 else 1
-    finally:
-        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        traceback.print_exc()
+        rc = -1
+    if hooks.error:
+        print(hooks.error, file=sys.stderr)
+    if rc != 0:
+        # the other shards may be waiting in a collective this one will never join: leave at once, without the
+        # process-group teardown (which can block on them), so that the launcher ends the whole job
+        if quiet is not None:
+            quiet.seek(0)
+            sys.stderr.write(quiet.read().decode(errors="replace")[-4000:])
+        print(f"amplisolve_amd.multi: shard {rank} failed (code {rc})", file=sys.stderr)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
+    dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

@@ -85,3 +85,15 @@ def test_variant_calling_sharded_equals_one_process(tmp_path, world):
         assert strip_dates((out / n).read_text()) == strip_dates((one / n).read_text())
     assert not [n for n in os.listdir(out) if ".part" in n]
     assert os.path.exists(out / "AmpliSolveVariantCalling_interm_files" / "dummyVCF_1.vcf")
+
+
+def test_failing_shard_ends_the_job(tmp_path):
+    """A shard that cannot read its input fails the whole launch promptly (no hang in a collective) with the reason."""
+    d = f"{G}/toy_subset"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", "-m", "amplisolve_amd.multi", "AmpliSolveVariantCalling", f"errorFile={tmp_path}/missing_table.txt",
+           f"tumour_dir={d}/TUMOUR", f"output_dir={tmp_path}/o", "coverage_cutoff=100", "p_value=0.05"]
+    e = dict(os.environ, AMPLISOLVE_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    assert r.returncode != 0
+    assert "failed" in r.stderr and "Something went wrong" in (r.stdout + r.stderr)
