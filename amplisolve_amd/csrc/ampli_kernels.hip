@@ -834,6 +834,21 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
 
     // one sample row in registers + the next one in flight; every lane group walks its own chunk, the trip count
     // (chunk_len) is wave-uniform and rows past a group's chunk are loaded clamped and not visited
+#if defined(AMPLI_EXP_U16)
+    // timing experiment: 16-byte records (8 x u16, 0xFFFF in field 0 = absent)
+    const size_t row_stride = (size_t)R;
+    const int4 *q = recs + ((size_t)min(s0, S - 1) * R + p);
+    int4 n0 = ld_stream(q), n1 = n0;
+    for (int i = 0; i < chunk_len; ++i) {
+        const int s = s0 + i;
+        int4 c0 = make_int4(n0.x & 0xFFFF, (unsigned)n0.x >> 16, n0.y & 0xFFFF, (unsigned)n0.y >> 16);
+        const int4 c1 = make_int4(n0.z & 0xFFFF, (unsigned)n0.z >> 16, n0.w & 0xFFFF, (unsigned)n0.w >> 16);
+        if (c0.x == 0xFFFF) c0.x = AMPLI_ABSENT;
+        if (i + 1 < chunk_len) {
+            if (s + 1 < S) q += row_stride;
+            n0 = ld_stream(q);
+        }
+#else
     const size_t row_stride = (size_t)R * 2;
     const int4 *q = recs + ((size_t)min(s0, S - 1) * R + p) * 2;
     int4 n0 = ld_stream(q), n1 = ld_stream(q + 1);
@@ -845,6 +860,7 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
             n0 = ld_stream(q);
             n1 = ld_stream(q + 1);
         }
+#endif
         if (s < s1) {
             if (FAST) visit_fast(f, c0, c1, first_sample + s, C, cov);
             else visit_record(a, c0, c1, first_sample + s, C, cov);
