@@ -116,6 +116,27 @@ class Context:
     def sync(self):
         self._check(self.lib.ampli_sync(self.h))
 
+    # ---- record layout (include/amplisolve_hip.h: AMPLI_RECORDS_I32 / AMPLI_RECORDS_U16) ----
+    def _rec_dtype(self):
+        import torch
+
+        return torch.int16 if getattr(self, "_u16", False) else torch.int32
+
+    def set_record_layout(self, u16: bool):
+        """Every record tensor handed to this context from now on is int16 [S, R, 8] (u16=True) or int32 [S, R, 8]."""
+        self._check(self.lib.ampli_set_record_layout(self.h, 1 if u16 else 0))
+        self._u16 = bool(u16)
+
+    def pack16(self, recs):
+        """int32 [S, R, 8] records -> (int16 [S, R, 8] records, fits): fits is False when a count exceeds 65534."""
+        import torch
+
+        assert recs.dtype == torch.int32 and recs.is_cuda and recs.is_contiguous() and recs.shape[-1] == 8
+        out = torch.empty(recs.shape, dtype=torch.int16, device=recs.device)
+        over = torch.zeros((1,), dtype=torch.int32, device=recs.device)
+        self._check(self.lib.ampli_records_pack16(self.h, _ptr(recs), recs.numel() // 8, _ptr(out), _ptr(over)))
+        return out, int(over.item()) == 0
+
     def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
         self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general) | (groups << 4)))
 
@@ -172,7 +193,7 @@ class Context:
                      first_sample: int = 0, acc: Acc | None = None) -> Acc:
         import torch
 
-        assert recs.dtype == torch.int32 and recs.is_cuda and recs.is_contiguous()
+        assert recs.dtype == self._rec_dtype() and recs.is_cuda and recs.is_contiguous()
         S = recs.shape[0]
         assert recs.numel() == S * (P + E) * 8
         if acc is None:
@@ -197,7 +218,7 @@ class Context:
         """Fused error_reduce + error_finalize (ampli_error_estimate); acc optional."""
         import torch
 
-        assert recs.dtype == torch.int32 and recs.is_cuda and recs.is_contiguous()
+        assert recs.dtype == self._rec_dtype() and recs.is_cuda and recs.is_contiguous()
         S = recs.shape[0]
         assert recs.numel() == S * (P + E) * 8
         if out is None:
@@ -284,7 +305,7 @@ class Context:
                      calls_buf=None, n_calls=None):
         import torch
 
-        assert trecs.dtype == torch.int32 and trecs.is_cuda and trecs.is_contiguous()
+        assert trecs.dtype == self._rec_dtype() and trecs.is_cuda and trecs.is_contiguous()
         T = trecs.shape[0]
         R = P + E
         assert trecs.numel() == T * R * 8

@@ -36,6 +36,7 @@ struct ampli_ctx {
     int reduce_splits = 0; // 0 = auto
     int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
+    int rec_u16 = 0;        // record layout of every d_recs / d_trecs argument: 0 = 8 x int32, 1 = 8 x uint16
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
     void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
     size_t queue_items = 0;
@@ -281,6 +282,14 @@ extern "C" int ampli_event_elapsed_ms(void *a, void *b, float *ms)
     return hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP;
 }
 
+extern "C" int ampli_set_record_layout(ampli_ctx *ctx, int32_t layout)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (layout != AMPLI_RECORDS_I32 && layout != AMPLI_RECORDS_U16) return fail(ctx, AMPLI_E_INVALID, "set_record_layout: unknown layout");
+    ctx->rec_u16 = layout == AMPLI_RECORDS_U16;
+    return AMPLI_OK;
+}
+
 extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general)
 {
     if (!ctx || reduce_sample_splits < 0) return AMPLI_E_INVALID;
@@ -320,6 +329,28 @@ __device__ __forceinline__ int4 ld_stream(const int4 *p)
 #else
     return *p;
 #endif
+}
+
+// Record layouts (include/amplisolve_hip.h): AMPLI_RECORDS_I32 = 8 x int32 (two int4 per record), AMPLI_RECORDS_U16 =
+// 8 x uint16 (one int4 per record, 0xFFFF in field 0 = absent).  A raw record is what a lane keeps in flight;
+// rec_decode widens it to the {forward int4, reverse int4} pair every visit function takes.
+template <bool U16> struct RawRec { int4 a, b; };
+template <bool U16> __device__ __forceinline__ RawRec<U16> rec_load(const int4 *__restrict__ recs, const size_t index)
+{
+    RawRec<U16> r;
+    if (U16) { r.a = ld_stream(recs + index); r.b = r.a; }
+    else { r.a = ld_stream(recs + index * 2); r.b = ld_stream(recs + index * 2 + 1); }
+    return r;
+}
+template <bool U16> __device__ __forceinline__ void rec_decode(const RawRec<U16> &r, int4 &fw, int4 &bw)
+{
+    if (U16) {
+        fw = make_int4(r.a.x & 0xFFFF, (int)((unsigned)r.a.x >> 16), r.a.y & 0xFFFF, (int)((unsigned)r.a.y >> 16));
+        bw = make_int4(r.a.z & 0xFFFF, (int)((unsigned)r.a.z >> 16), r.a.w & 0xFFFF, (int)((unsigned)r.a.w >> 16));
+        if (fw.x == 0xFFFF) fw.x = AMPLI_ABSENT;
+    } else {
+        fw = r.a; bw = r.b;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -803,7 +834,7 @@ __device__ __forceinline__ void lane_acc_shfl_down(const LaneAcc &a, LaneAcc &b,
 // workgroup (tile, split) owns chunk ((split*4 + w)*G + g)).  More, shorter waves for the same panel: the launch
 // then runs several balanced rounds instead of one and a half long ones (the fixed ~24 us of ramp + tail measured
 // at G = 1 shrinks with the wave lifetime).  A lane group still reads >= 512 contiguous bytes per sample row.
-template <bool FAST, int G>
+template <bool FAST, int G, bool U16>
 __global__ __launch_bounds__(256) void error_reduce_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
@@ -834,41 +865,26 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
 
     // one sample row in registers + the next one in flight; every lane group walks its own chunk, the trip count
     // (chunk_len) is wave-uniform and rows past a group's chunk are loaded clamped and not visited
-#if defined(AMPLI_EXP_U16)
-    // timing experiment: 16-byte records (8 x u16, 0xFFFF in field 0 = absent)
-    const size_t row_stride = (size_t)R;
-    const int4 *q = recs + ((size_t)min(s0, S - 1) * R + p);
-    int4 n0 = ld_stream(q), n1 = n0;
+    const size_t row_stride = (size_t)R; // in records
+    size_t qi = (size_t)min(s0, S - 1) * R + p;
+    RawRec<U16> nx = rec_load<U16>(recs, qi);
     for (int i = 0; i < chunk_len; ++i) {
         const int s = s0 + i;
-        int4 c0 = make_int4(n0.x & 0xFFFF, (unsigned)n0.x >> 16, n0.y & 0xFFFF, (unsigned)n0.y >> 16);
-        const int4 c1 = make_int4(n0.z & 0xFFFF, (unsigned)n0.z >> 16, n0.w & 0xFFFF, (unsigned)n0.w >> 16);
-        if (c0.x == 0xFFFF) c0.x = AMPLI_ABSENT;
-        if (i + 1 < chunk_len) {
-            if (s + 1 < S) q += row_stride;
-            n0 = ld_stream(q);
-        }
-#else
-    const size_t row_stride = (size_t)R * 2;
-    const int4 *q = recs + ((size_t)min(s0, S - 1) * R + p) * 2;
-    int4 n0 = ld_stream(q), n1 = ld_stream(q + 1);
-    for (int i = 0; i < chunk_len; ++i) {
-        const int s = s0 + i;
-        const int4 c0 = n0, c1 = n1;
+        int4 c0, c1;
+        rec_decode<U16>(nx, c0, c1);
         if (i + 1 < chunk_len) { // prefetch while this row is consumed
-            if (s + 1 < S) q += row_stride;
-            n0 = ld_stream(q);
-            n1 = ld_stream(q + 1);
+            if (s + 1 < S) qi += row_stride;
+            nx = rec_load<U16>(recs, qi);
         }
-#endif
         if (s < s1) {
             if (FAST) visit_fast(f, c0, c1, first_sample + s, C, cov);
             else visit_record(a, c0, c1, first_sample + s, C, cov);
             if (any_dup) { // extras of this position in the same sample, in file order
                 for (unsigned e = e0; e < e1; ++e) {
-                    const int4 *x = recs + ((size_t)s * R + (size_t)P + e) * 2;
-                    if (FAST) visit_fast(f, x[0], x[1], first_sample + s, C, cov);
-                    else visit_record(a, x[0], x[1], first_sample + s, C, cov);
+                    int4 x0, x1;
+                    rec_decode<U16>(rec_load<U16>(recs, (size_t)s * R + (size_t)P + e), x0, x1);
+                    if (FAST) visit_fast(f, x0, x1, first_sample + s, C, cov);
+                    else visit_record(a, x0, x1, first_sample + s, C, cov);
                 }
             }
         }
@@ -1162,7 +1178,7 @@ __device__ __forceinline__ long long call_slot(unsigned long long *__restrict__ 
 
 constexpr int PC_SAMPLES = 4;
 
-template <int MODE>
+template <int MODE, bool U16>
 __global__ __launch_bounds__(256) void poisson_call_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
@@ -1185,7 +1201,8 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
         const int t = t0 + dt;
         if (t >= T) break;
         const size_t o = (size_t)t * R + r;
-        const int4 r0 = recs[o * 2], r1 = recs[o * 2 + 1];
+        int4 r0, r1;
+        rec_decode<U16>(rec_load<U16>(recs, o), r0, r1);
         const bool present = r0.x != AMPLI_ABSENT;
         const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
         const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
@@ -1271,6 +1288,7 @@ struct PcItem { // 32 bytes, self-contained: the drain kernel needs no second lo
     float e_fw, e_bw;           // effective errors (ampli_effective_err)
 };
 
+template <bool U16>
 __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const int rows_per_block, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code,
@@ -1322,15 +1340,14 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     }
     const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS; // workgroups dealt round-robin
 
-    const size_t row_stride = (size_t)R * 2;
-    const int4 *row = recs + ((size_t)t0 * R + r) * 2;
-    int4 n0 = ld_stream(row), n1 = ld_stream(row + 1);
+    size_t ri = (size_t)t0 * R + r; // record index
+    RawRec<U16> nx = rec_load<U16>(recs, ri);
     for (int dt = 0; dt < nt_rows; ++dt) {
-        const int4 r0v = n0, r1v = n1;
+        int4 r0v, r1v;
+        rec_decode<U16>(nx, r0v, r1v);
         if (dt + 1 < nt_rows) { // prefetch the next sample row
-            row += row_stride;
-            n0 = ld_stream(row);
-            n1 = ld_stream(row + 1);
+            ri += (size_t)R;
+            nx = rec_load<U16>(recs, ri);
         }
         const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
         const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
@@ -1481,6 +1498,24 @@ __global__ void synth_fill_kernel(int4 *recs, const long long P, const int n_sam
     recs[o + 1] = make_int4(rec[4], rec[5], rec[6], rec[7]);
 }
 
+// 8 x int32 records -> 8 x uint16 records (AMPLI_ABSENT -> 0xFFFF); *overflow is raised for a count above 65534
+__global__ __launch_bounds__(256) void records_pack16_kernel(const int4 *__restrict__ in, const long long n, uint4 *__restrict__ out,
+                                                             int *__restrict__ overflow)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 a = in[i * 2], b = in[i * 2 + 1];
+    const bool absent = a.x == AMPLI_ABSENT;
+    const unsigned v[8] = {absent ? 0xFFFFu : (unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w,
+                           (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= (j == 0 && absent) ? false : v[j] > 65534u;
+    if (bad) atomicOr(overflow, 1);
+    out[i] = make_uint4((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16), (v[4] & 0xFFFFu) | (v[5] << 16),
+                        (v[6] & 0xFFFFu) | (v[7] << 16));
+}
+
 __global__ void synth_ref_kernel(unsigned char *ref, const long long P, const unsigned long long seed)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1592,10 +1627,15 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         kfin.slice_len = 0;
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
-#define AMPLI_LAUNCH_REDUCE(FASTV, GV)                                                                                       \
-    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, \
+#define AMPLI_LAUNCH_REDUCE_L(FASTV, GV, UV)                                                                                      \
+    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, \
                        (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],  \
                        off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin)
+#define AMPLI_LAUNCH_REDUCE(FASTV, GV)                           \
+    do {                                                         \
+        if (ctx->rec_u16) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, true); \
+        else AMPLI_LAUNCH_REDUCE_L(FASTV, GV, false);            \
+    } while (0)
     if (fast) {
         if (G == 4) AMPLI_LAUNCH_REDUCE(true, 4);
         else if (G == 2) AMPLI_LAUNCH_REDUCE(true, 2);
@@ -1606,6 +1646,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         else AMPLI_LAUNCH_REDUCE(false, 1);
     }
 #undef AMPLI_LAUNCH_REDUCE
+#undef AMPLI_LAUNCH_REDUCE_L
     int rc = check_launch(ctx, "error_reduce_kernel");
     if (rc) return rc;
     if (splits > 1) {
@@ -1844,15 +1885,17 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
     dim3 grid((unsigned)((R + 255) / 256), (unsigned)((T + PC_SAMPLES - 1) / PC_SAMPLES));
     if (d_n_calls && (mode == AMPLI_POISSON_FULL || d_af)) // the two-kernel path resets the counters in-kernel
         HIP_TRY(ctx, hipMemsetAsync(d_n_calls, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
-    if (mode == AMPLI_POISSON_FULL)
-        hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_FULL>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
-                           (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
-                           (long long)capacity, d_n_calls, d_q, d_af);
-    else if (d_af) // dense VAFs are a validation output: literal per-lane kernel
-        hipLaunchKernelGGL(poisson_call_kernel<AMPLI_POISSON_PREFILTER>, grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs,
-                           (long long)P, (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls,
-                           (long long)capacity, d_n_calls, d_q, d_af);
-    else {
+#define AMPLI_LAUNCH_PC(MODEV, UV)                                                                                              \
+    hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,  \
+                       (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls, (long long)capacity, \
+                       d_n_calls, d_q, d_af)
+    if (mode == AMPLI_POISSON_FULL) {
+        if (ctx->rec_u16) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, true);
+        else AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, false);
+    } else if (d_af) { // dense VAFs are a validation output: literal per-lane kernel
+        if (ctx->rec_u16) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, true);
+        else AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, false);
+    } else {
         // tumour rows per workgroup: short workgroups win (measured on config 3: 4-6 rows 0.091 ms, 20 rows 0.098 ms,
         // 96 rows 0.167 ms -- many small workgroups keep every CU fed through the tail); thresholds are re-read per
         // workgroup from L2.  Only very large panels get longer workgroups, to bound the grid.
@@ -1896,9 +1939,14 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         else
             ctx->queue_parity ^= 1;
         dim3 qgrid((unsigned)tiles, (unsigned)gy);
-        hipLaunchKernelGGL(poisson_stream_kernel, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P, (long long)E,
-                           d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
-                           (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
+        if (ctx->rec_u16)
+            hipLaunchKernelGGL(poisson_stream_kernel<true>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,
+                               (long long)E, d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
+                               (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
+        else
+            hipLaunchKernelGGL(poisson_stream_kernel<false>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,
+                               (long long)E, d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
+                               (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;
         hipStream_t dstream = ctx->stream;
@@ -1944,6 +1992,17 @@ extern "C" int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int3
     hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)n_samples), dim3(256), 0, ctx->stream,
                        (int4 *)d_recs, (long long)P, (int)n_samples, (int)first_sample, (unsigned long long)seed, (int)depth, (int)tumour);
     return check_launch(ctx, "synth_fill_kernel");
+}
+
+extern "C" int ampli_records_pack16(ampli_ctx *ctx, const int32_t *d_recs32, int64_t n_records, void *d_recs16, int32_t *d_overflow)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_recs32 || !d_recs16 || !d_overflow || n_records <= 0 || ((uintptr_t)d_recs32 & 15) || ((uintptr_t)d_recs16 & 15))
+        return fail(ctx, AMPLI_E_INVALID, "records_pack16: bad argument (16-byte aligned buffers, n_records > 0, overflow word)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(records_pack16_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, (const int4 *)d_recs32,
+                       (long long)n_records, (uint4 *)d_recs16, d_overflow);
+    return check_launch(ctx, "records_pack16_kernel");
 }
 
 extern "C" int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t seed)

@@ -48,6 +48,10 @@ extern "C" {
 
 #define AMPLI_ABI_VERSION 1
 #define AMPLI_ABSENT INT32_MIN
+/* record layouts: the default, and a compact one for cohorts whose every count is <= 65534 (half the HBM bytes):
+ *   uint16 recs[n_samples][R][8], same field order, absent record: recs[..][0] == 0xFFFF */
+#define AMPLI_RECORDS_I32 0
+#define AMPLI_RECORDS_U16 1
 
 #define AMPLI_OK 0
 #define AMPLI_E_INVALID (-1)  /* bad argument */
@@ -69,6 +73,11 @@ int ampli_device_count(void);
  * non-blocking stream (which does not synchronise with the null stream). */
 #define AMPLI_STREAM_OWN ((void *)(intptr_t)-1)
 int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **out);
+/* layout of every record array (d_recs / d_trecs) handed to this context from now on; results are identical */
+int ampli_set_record_layout(ampli_ctx *ctx, int32_t layout);
+/* device-side conversion 8 x int32 -> 8 x uint16 of n_records records; *d_overflow is OR-ed with 1 when a count does
+ * not fit (the caller then stays with AMPLI_RECORDS_I32) */
+int ampli_records_pack16(ampli_ctx *ctx, const int32_t *d_recs32, int64_t n_records, void *d_recs16, int32_t *d_overflow);
 void ampli_ctx_destroy(ampli_ctx *ctx);
 const char *ampli_last_error(ampli_ctx *ctx);
 int ampli_sync(ampli_ctx *ctx);        /* hipStreamSynchronize */

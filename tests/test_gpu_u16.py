@@ -1,0 +1,158 @@
+"""The compact record layout (AMPLI_RECORDS_U16: 8 x uint16 per record, half the HBM bytes) gives the same results
+as the oracle on the same records, through every kernel that reads records."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as orc
+from tests.helpers import edge_case_recs, synth_recs, synth_ref
+from tests.test_gpu_parity import _t, assert_acc_equal, assert_final_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx16():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from amplisolve_amd import Context
+
+    c = Context(0)
+    c.set_record_layout(True)
+    yield c
+    c.close()
+
+
+def to16(ctx16, recs):
+    """int32 numpy records -> int16 device records through ampli_records_pack16 (and cross-checked on the host)."""
+    r16, fits = ctx16.pack16(_t(recs))
+    assert fits
+    host = recs.astype(np.int64)
+    host[recs[..., 0] == np.iinfo(np.int32).min, 0] = 0xFFFF
+    assert np.array_equal(r16.cpu().numpy().view(np.uint16), host.astype(np.uint16))
+    return r16
+
+
+def test_pack16_flags_counts_that_do_not_fit(ctx16):
+    recs = synth_recs(100, 3)
+    recs[1, 7, 2] = 65534
+    _, fits = ctx16.pack16(_t(recs))
+    assert fits
+    recs[2, 50, 5] = 65535  # would collide with nothing, but the absent marker lives at this value in field 0: not allowed anywhere
+    _, fits = ctx16.pack16(_t(recs))
+    assert not fits
+
+
+@pytest.mark.parametrize("general", [False, True])
+@pytest.mark.parametrize("P,S,splits,groups", [(1, 1, 0, 0), (63, 3, 0, 1), (65, 5, 2, 2), (1000, 33, 3, 4), (4097, 37, 0, 0), (777, 130, 0, 0),
+                                               (15, 300, 2, 0)])
+def test_error_reduce_u16(ctx16, P, S, splits, groups, general):
+    recs = synth_recs(P, S)
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    ctx16.set_tuning(splits, general=general, groups=groups)
+    acc = ctx16.error_reduce(to16(ctx16, recs), P, 0.002, 100)
+    ctx16.set_tuning(0)
+    assert ctx16.flags() == 0
+    assert_acc_equal(acc, ref)
+    assert_final_equal(ctx16.error_finalize(acc, 0.002, 100), orc.error_finalize(ref))
+    assert_final_equal(ctx16.error_estimate(to16(ctx16, recs), P, 0.002, 100), orc.error_finalize(ref))
+
+
+@pytest.mark.parametrize("C,cov", [(0.002, 100), (0.0005, 1), (0.002, 1000)])
+def test_error_reduce_u16_edge_cases_with_extras(ctx16, C, cov):
+    rng = np.random.default_rng(31)
+    P, S = 300, 13
+    mult = np.zeros(P, np.int64)
+    mult[rng.choice(P, 40, replace=False)] = 1
+    mult[rng.choice(P, 5, replace=False)] = 2
+    dup_off = np.concatenate([[0], np.cumsum(mult)]).astype(np.uint32)
+    E = int(dup_off[-1])
+    recs = edge_case_recs(P + E, S, rng)  # depths up to 33395 per strand: fits
+    ref = orc.error_reduce(recs, P, C, cov, E=E, dup_off=dup_off)
+    for general in (False, True):
+        ctx16.set_tuning(0, general=general)
+        acc = ctx16.error_reduce(to16(ctx16, recs), P, C, cov, E=E, dup_off=_t(dup_off))
+        ctx16.set_tuning(0)
+        assert_acc_equal(acc, ref)
+    assert_final_equal(ctx16.error_finalize(acc, C, cov), orc.error_finalize(ref))
+
+
+def test_poisson_call_u16(ctx16):
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    rng = np.random.default_rng(13)
+    P, T, E = 400, 6, 37
+    trecs = edge_case_recs(P + E, T, rng)
+    trecs[:, ::7, :] = np.array([30, 0, 0, 400, 25, 0, 0, 380], np.int32)
+    thr = rng.choice(np.array([0.002, 0.01, 0.0, -1.0, 0.000731, 0.05], np.float32), size=(2, 4, P)).astype(np.float32)
+    ref_code = rng.integers(0, 4, P).astype(np.uint8)
+    ref_code[::11] = 255
+    ext_pos = rng.integers(0, P, E).astype(np.uint32)
+    exp = orc.poisson_call(trecs, P, thr, ref_code, 100, E=E, ext_pos=ext_pos)
+    assert exp["call_mask"].any()
+    t16 = to16(ctx16, trecs)
+    for mode in (POISSON_FULL, POISSON_PREFILTER):
+        res = ctx16.poisson_call(t16, P, _t(thr), _t(ref_code), 100, mode=mode, E=E, ext_pos=_t(ext_pos), dense_q=(mode == POISSON_FULL),
+                                 dense_af=(mode == POISSON_FULL), capacity=1 << 17)
+        assert np.array_equal(res["call_mask"].cpu().numpy(), exp["call_mask"])
+        if mode == POISSON_FULL:
+            q = res["q"].cpu().numpy()
+            assert np.array_equal(q == -1, exp["q"] == -1) and np.max(np.abs(q - exp["q"])) <= 1e-5
+            assert np.array_equal(res["af"].cpu().numpy().view(np.int32), exp["af"].view(np.int32))
+        calls = ctx16.read_calls(res)
+        assert len(calls) == sum(bin(int(v)).count("1") for v in exp["call_mask"].ravel())
+        for c in calls:
+            assert exp["call_mask"][c["sample"], c["record"]] >> c["alt"] & 1
+            assert abs(c["q_fw"] - exp["q"][c["sample"], c["record"], c["alt"], 0]) <= 1e-5
+            assert np.float32(c["af"]) == exp["af"][c["sample"], c["record"], c["alt"], 0]
+
+
+def test_sliced_merge_u16(ctx16):
+    import torch
+
+    from amplisolve_amd.dist import shard_range, slice_geometry
+
+    P, S, n = 1000, 37, 3
+    recs = synth_recs(P, S)
+    ref = orc.error_finalize(orc.error_reduce(recs, P))
+    L, _, _, bb = slice_geometry(P, n)
+    sums, gms = [], []
+    for r in range(n):
+        a, b = shard_range(S, r, n)
+        s = torch.zeros(n * 21 * L, dtype=torch.float64, device="cuda")
+        g = torch.zeros(n * 8 * L, dtype=torch.float32, device="cuda")
+        ctx16.error_reduce_sliced(to16(ctx16, recs[a:b]), P, n, s, g, first_sample=a)
+        sums.append(s)
+        gms.append(g)
+    total = torch.stack(sums).sum(0).view(n, 21 * L)
+    blocks = torch.zeros(n * bb, dtype=torch.uint8, device="cuda")
+    for k in range(n):
+        recv = torch.stack([g.view(n, 8 * L)[k] for g in gms]).contiguous()
+        ctx16.error_finalize_slice(P, n, k, total[k].contiguous(), recv, blocks[k * bb:(k + 1) * bb])
+    assert_final_equal(ctx16.error_table_unslice(P, n, blocks), ref)
+
+
+def test_config3_full_size_u16_equals_i32(ctx, ctx16):
+    """BASELINE config 3 at full size: both layouts, every output plane, the call mask and the call list."""
+    import torch
+
+    P, S, T = 100_000, 256, 96
+    normals = ctx.synth_fill(P, S, first_sample=0, depth=2000)
+    tumours = ctx.synth_fill(P, T, first_sample=0, depth=2000, tumour=True)
+    ref_code = ctx.synth_ref(P)
+    a = ctx.error_estimate(normals, P)
+    n16, fits = ctx16.pack16(normals)
+    assert fits
+    b = ctx16.error_estimate(n16, P)
+    for k in ("rate", "thr", "code", "germ_present"):
+        assert torch.equal(getattr(a, k).view(torch.uint8), getattr(b, k).view(torch.uint8)), k
+    m = a.germ_present > 0
+    assert torch.equal(a.germ_val[m], b.germ_val[m])
+    t16, fits = ctx16.pack16(tumours)
+    assert fits
+    ra = ctx.poisson_call(tumours, P, a.thr, ref_code, 100, capacity=1 << 20)
+    rb = ctx16.poisson_call(t16, P, a.thr, ref_code, 100, capacity=1 << 20)
+    assert torch.equal(ra["call_mask"], rb["call_mask"]) and int(ra["call_mask"].count_nonzero()) > 1000
+    ca, cb = ctx.read_calls(ra), ctx16.read_calls(rb)
+    assert len(ca) > 1000 and ca.tobytes() == cb.tobytes()
