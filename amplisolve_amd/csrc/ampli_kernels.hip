@@ -681,6 +681,9 @@ struct FastAcc {
     int gn[4], gfx[4], gfd[4], gfi[4]; // germ-max: qualifying count; first record as a fraction + its sample index
     int gbx[4], gbd[4];                // best later record as a fraction (0/1 until one exists)
     int bad;                           // a depth beyond FAST_COUNT_LIMIT was seen
+    // wave-uniform: lanes whose gn[nt] is still 0.  Lets the steady state of the Germ_Max tracking skip the
+    // "first qualifying record" bookkeeping (LEAN visits only; kept in scalar registers)
+    unsigned long long zmask[4];
 };
 
 __device__ __forceinline__ void fast_init(FastAcc &a)
@@ -693,6 +696,7 @@ __device__ __forceinline__ void fast_init(FastAcc &a)
         a.cnt[nt] = 0;
         a.gn[nt] = 0; a.gfx[nt] = 0; a.gfd[nt] = 1; a.gfi[nt] = 0x7fffffff;
         a.gbx[nt] = 0; a.gbd[nt] = 1;
+        a.zmask[nt] = ~0ull;
     }
     a.nrec = 0;
     a.bad = 0;
@@ -704,6 +708,8 @@ __device__ __forceinline__ unsigned long long mul24x24(int a, int b)
     return (unsigned long long)((unsigned)a & 0xFFFFFFu) * (unsigned long long)((unsigned)b & 0xFFFFFFu);
 }
 
+// LEAN: the caller guarantees a full, converged wave (no lane group / extras divergence) and keeps a.zmask current.
+template <bool LEAN>
 __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4 r1, const int sample, const float C,
                                            const int cov)
 {
@@ -733,10 +739,26 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
         }
         const int x = fw[nt] + bw[nt];
 #if defined(AMPLI_DIAG_NOGM)
-        if (covok && x == -77) {
+        const bool pass = covok && x == -77;
 #else
-        if (covok && x <= lim_rd) { // EE:1251: float(X)/float(RD) <= 0.05
+        const bool pass = covok && x <= lim_rd; // EE:1251: float(X)/float(RD) <= 0.05
 #endif
+        if (LEAN) {
+            // straight-line steady state: every passing lane already holds its first record, so only "x/RD > best" is
+            // left (EE:1266).  A lane meeting its FIRST qualifying record (its AF is dropped by the reference,
+            // EE:1258-1261) is dealt with in the rare wave-uniform block and taken out of this row's comparison.
+            bool cand = pass;
+            if (__builtin_amdgcn_ballot_w64(pass) & a.zmask[nt]) {
+                const bool is_first = pass && a.gn[nt] == 0;
+                if (is_first) { a.gfx[nt] = x; a.gfd[nt] = RD; a.gfi[nt] = sample; a.gn[nt] = 1; }
+                a.zmask[nt] = __builtin_amdgcn_ballot_w64(a.gn[nt] == 0);
+                cand = pass && !is_first;
+            }
+            const bool better = cand && mul24x24(x, a.gbd[nt]) > mul24x24(a.gbx[nt], RD); // ties keep the value
+            a.gbx[nt] = better ? x : a.gbx[nt];
+            a.gbd[nt] = better ? RD : a.gbd[nt];
+            a.gn[nt] += cand ? 1 : 0;
+        } else if (pass) {
             if (a.gn[nt] == 0) {    // first qualifying record: its AF is dropped by the reference (EE:1258-1261)
                 a.gfx[nt] = x; a.gfd[nt] = RD; a.gfi[nt] = sample;
             } else if (mul24x24(x, a.gbd[nt]) > mul24x24(a.gbx[nt], RD)) { // x/RD > best: EE:1266 (ties keep the value)
@@ -844,7 +866,7 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     constexpr int W = 64 / G; // positions per wave
     __shared__ RedShared sh;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, and the compiler may know it
     const int group = lane / W;
     const long long p_raw = (long long)blockIdx.x * W + (lane % W);
     const bool valid = p_raw < P;
@@ -877,14 +899,20 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
             nx = rec_load<U16>(recs, qi);
         }
         if (s < s1) {
-            if (FAST) visit_fast(f, c0, c1, first_sample + s, C, cov);
+            // G == 1: s0 / s1 are wave-uniform, the whole wave is here -> the lean Germ_Max path.  Only the 16-byte
+            // layout is VALU-bound enough to profit; with 32-byte records the extra registers cost a wave of occupancy
+            if (FAST) visit_fast<G == 1 && U16>(f, c0, c1, first_sample + s, C, cov);
             else visit_record(a, c0, c1, first_sample + s, C, cov);
             if (any_dup) { // extras of this position in the same sample, in file order
                 for (unsigned e = e0; e < e1; ++e) {
                     int4 x0, x1;
                     rec_decode<U16>(rec_load<U16>(recs, (size_t)s * R + (size_t)P + e), x0, x1);
-                    if (FAST) visit_fast(f, x0, x1, first_sample + s, C, cov);
+                    if (FAST) visit_fast<false>(f, x0, x1, first_sample + s, C, cov); // per-lane trip counts: no wave-level shortcuts
                     else visit_record(a, x0, x1, first_sample + s, C, cov);
+                }
+                if (FAST && G == 1 && U16) { // the extras may have given lanes their first record
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) f.zmask[nt] = __builtin_amdgcn_ballot_w64(f.gn[nt] == 0);
                 }
             }
         }
