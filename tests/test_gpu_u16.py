@@ -156,3 +156,23 @@ def test_config3_full_size_u16_equals_i32(ctx, ctx16):
     assert torch.equal(ra["call_mask"], rb["call_mask"]) and int(ra["call_mask"].count_nonzero()) > 1000
     ca, cb = ctx.read_calls(ra), ctx16.read_calls(rb)
     assert len(ca) > 1000 and ca.tobytes() == cb.tobytes()
+
+
+def test_error_reduce_u16_largest_depths(ctx16):
+    """Counts at the top of the uint16 range (total depths of 350-400 k): sums, gates and the Germ_Max products stay exact."""
+    P, S = 640, 40
+    recs = synth_recs(P, S)
+    rng = np.random.default_rng(77)
+    for s_i, p_i in zip(rng.integers(2, S, 60), rng.integers(0, P, 60)):
+        t = int(rng.integers(500, 6000))
+        recs[s_i, p_i] = [60000, 60000, 60000, t, 59000, 61000, 60500, t + 7]      # RD ~ 366 k, T allele at 0.3 - 3 %
+    recs[1, 5] = [65534, 65534, 65534, 3000, 65534, 65534, 65534, 3100]             # RD = 399 304 in the second row of a chunk
+    recs[S - 1, 5] = [2000, 3, 1, 60, 1900, 2, 0, 55]                               # a later, ordinary record must still compare right
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    for general, groups in ((False, 1), (False, 2), (True, 1)):
+        ctx16.set_tuning(0, general=general, groups=groups)
+        acc = ctx16.error_reduce(to16(ctx16, recs), P, 0.002, 100)
+        ctx16.set_tuning(0)
+        assert ctx16.flags() == 0
+        assert_acc_equal(acc, ref)
+    assert_final_equal(ctx16.error_estimate(to16(ctx16, recs), P, 0.002, 100), orc.error_finalize(ref))
