@@ -489,9 +489,8 @@ def main():
         if args.config == "c3" and world == 1 and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
-                key = [k for k in pm if dom.split("+")[0].split("<")[0] in k]
                 traffic = sum(pm[k].get("hbm_bytes_per_launch", 0.0) for k in pm
-                              if any(part.split("<")[0] in k for part in dom.split("+"))) or None
+                              if any(part in k for part in dom.split("+"))) or None
             except Exception:
                 traffic = None
         out = {

@@ -25,9 +25,9 @@ def strip_dates(text):
     return "\n".join(l for l in text.splitlines() if not l.startswith("##fileDate="))
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_error_estimation_sharded_equals_one_process(tmp_path, world):
-    """5 normal files over 2, 3 and 5 processes (the GPU box allows 6 processes on its card, pytest included)."""
+    """5 normal files over 2, 3 and 4 processes (the GPU box allows 6 processes on its card, pytest included)."""
     d = f"{G}/toy_subset"
     out = tmp_path / "multi"
     torchrun(world, 29541 + world, ["AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
@@ -66,9 +66,9 @@ def test_error_estimation_sharded_edge_cases(tmp_path):
     assert (out / "positionSpecificNoise_0.0005.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0005_cov1.txt").read()
 
 
-@pytest.mark.parametrize("world", [2, 3, 5])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_variant_calling_sharded_equals_one_process(tmp_path, world):
-    """3 tumour files (one without any call) over 2, 3 and 5 processes: Summary and every VCF as the one-process run."""
+    """3 tumour files (one without any call) over 2, 3 and 4 processes: Summary and every VCF as the one-process run."""
     d = f"{G}/toy_subset"
     table = f"{d}/expected_positionSpecificNoise_0.0020.txt"
     one = tmp_path / "one"
