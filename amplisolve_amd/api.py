@@ -117,15 +117,24 @@ class Context:
         self._check(self.lib.ampli_sync(self.h))
 
     # ---- record layout (include/amplisolve_hip.h: AMPLI_RECORDS_I32 / AMPLI_RECORDS_U16) ----
+    LAYOUTS = {"i32": 0, "u16": 1, "u24": 2}
+
     def _rec_dtype(self):
         import torch
 
-        return torch.int16 if getattr(self, "_u16", False) else torch.int32
+        return {"i32": torch.int32, "u16": torch.int16, "u24": torch.uint8}[getattr(self, "_layout", "i32")]
 
-    def set_record_layout(self, u16: bool):
-        """Every record tensor handed to this context from now on is int16 [S, R, 8] (u16=True) or int32 [S, R, 8]."""
-        self._check(self.lib.ampli_set_record_layout(self.h, 1 if u16 else 0))
-        self._u16 = bool(u16)
+    def _rec_elems(self) -> int:
+        """elements of _rec_dtype per record"""
+        return 24 if getattr(self, "_layout", "i32") == "u24" else 8
+
+    def set_record_layout(self, layout):
+        """Every record tensor handed to this context from now on is int32 [S, R, 8] ("i32"), int16 [S, R, 8] ("u16")
+        or uint8 [S, R, 24] ("u24": 8 little-endian 24-bit fields).  True / False select "u16" / "i32"."""
+        if isinstance(layout, bool):
+            layout = "u16" if layout else "i32"
+        self._check(self.lib.ampli_set_record_layout(self.h, self.LAYOUTS[layout]))
+        self._layout = layout
 
     def pack16(self, recs):
         """int32 [S, R, 8] records -> (int16 [S, R, 8] records, fits): fits is False when a count exceeds 65534."""
@@ -136,6 +145,20 @@ class Context:
         over = torch.zeros((1,), dtype=torch.int32, device=recs.device)
         self._check(self.lib.ampli_records_pack16(self.h, _ptr(recs), recs.numel() // 8, _ptr(out), _ptr(over)))
         return out, int(over.item()) == 0
+
+    def pack24(self, recs):
+        """int32 [S, R, 8] records -> (uint8 [S, R, 24] records, fits): fits is False when a count exceeds 2^24 - 2."""
+        import torch
+
+        assert recs.dtype == torch.int32 and recs.is_cuda and recs.is_contiguous() and recs.shape[-1] == 8
+        out = torch.empty(tuple(recs.shape[:-1]) + (24,), dtype=torch.uint8, device=recs.device)
+        over = torch.zeros((1,), dtype=torch.int32, device=recs.device)
+        self._check(self.lib.ampli_records_pack24(self.h, _ptr(recs), recs.numel() // 8, _ptr(out), _ptr(over)))
+        return out, int(over.item()) == 0
+
+    def pack(self, recs, layout: str):
+        """recs (int32) in `layout`: (tensor, fits)"""
+        return (recs, True) if layout == "i32" else (self.pack16(recs) if layout == "u16" else self.pack24(recs))
 
     def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
         self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general) | (groups << 4)))
@@ -195,7 +218,7 @@ class Context:
 
         assert recs.dtype == self._rec_dtype() and recs.is_cuda and recs.is_contiguous()
         S = recs.shape[0]
-        assert recs.numel() == S * (P + E) * 8
+        assert recs.numel() == S * (P + E) * self._rec_elems()
         if acc is None:
             acc = self.new_acc(P)
         self._check(self.lib.ampli_error_reduce(self.h, _ptr(recs), P, E, _ptr(dup_off), S, first_sample,
@@ -220,7 +243,7 @@ class Context:
 
         assert recs.dtype == self._rec_dtype() and recs.is_cuda and recs.is_contiguous()
         S = recs.shape[0]
-        assert recs.numel() == S * (P + E) * 8
+        assert recs.numel() == S * (P + E) * self._rec_elems()
         if out is None:
             out = self._new_error_table(P)
         self._check(self.lib.ampli_error_estimate(self.h, _ptr(recs), P, E, _ptr(dup_off), S, C_value, cov,
@@ -308,7 +331,7 @@ class Context:
         assert trecs.dtype == self._rec_dtype() and trecs.is_cuda and trecs.is_contiguous()
         T = trecs.shape[0]
         R = P + E
-        assert trecs.numel() == T * R * 8
+        assert trecs.numel() == T * R * self._rec_elems()
         d = self.device
         if call_mask is None:
             call_mask = torch.empty(((T * R + 3) // 4 * 4,), dtype=torch.uint8, device=d)[: T * R].view(T, R)

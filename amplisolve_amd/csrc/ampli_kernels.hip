@@ -36,7 +36,7 @@ struct ampli_ctx {
     int reduce_splits = 0; // 0 = auto
     int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
-    int rec_u16 = 0;        // record layout of every d_recs / d_trecs argument: 0 = 8 x int32, 1 = 8 x uint16
+    int rec_layout = 0;     // record layout of every d_recs / d_trecs argument: AMPLI_RECORDS_I32 / _U16 / _U24
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
     void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
     size_t queue_items = 0;
@@ -285,8 +285,9 @@ extern "C" int ampli_event_elapsed_ms(void *a, void *b, float *ms)
 extern "C" int ampli_set_record_layout(ampli_ctx *ctx, int32_t layout)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (layout != AMPLI_RECORDS_I32 && layout != AMPLI_RECORDS_U16) return fail(ctx, AMPLI_E_INVALID, "set_record_layout: unknown layout");
-    ctx->rec_u16 = layout == AMPLI_RECORDS_U16;
+    if (layout != AMPLI_RECORDS_I32 && layout != AMPLI_RECORDS_U16 && layout != AMPLI_RECORDS_U24)
+        return fail(ctx, AMPLI_E_INVALID, "set_record_layout: unknown layout");
+    ctx->rec_layout = layout;
     return AMPLI_OK;
 }
 
@@ -331,20 +332,43 @@ __device__ __forceinline__ int4 ld_stream(const int4 *p)
 #endif
 }
 
-// Record layouts (include/amplisolve_hip.h): AMPLI_RECORDS_I32 = 8 x int32 (two int4 per record), AMPLI_RECORDS_U16 =
-// 8 x uint16 (one int4 per record, 0xFFFF in field 0 = absent).  A raw record is what a lane keeps in flight;
-// rec_decode widens it to the {forward int4, reverse int4} pair every visit function takes.
-template <bool U16> struct RawRec { int4 a, b; };
-template <bool U16> __device__ __forceinline__ RawRec<U16> rec_load(const int4 *__restrict__ recs, const size_t index)
+// Record layouts (include/amplisolve_hip.h), template parameter LAY:
+//   AMPLI_RECORDS_I32  8 x int32, two int4 per record                      (absent: INT32_MIN in field 0)
+//   AMPLI_RECORDS_U16  8 x uint16, one int4 per record                     (absent: 0xFFFF)
+//   AMPLI_RECORDS_U24  8 x 24-bit little-endian, 24 bytes = three 8-byte loads per record (absent: 0xFFFFFF)
+// A raw record is what a lane keeps in flight; rec_decode widens it to the {forward int4, reverse int4} pair every
+// visit function takes.
+template <int LAY> struct RawRec { int4 a, b; };
+template <> struct RawRec<AMPLI_RECORDS_U24> { uint2 a, b, c; };
+
+template <int LAY> __device__ __forceinline__ RawRec<LAY> rec_load(const int4 *__restrict__ recs, const size_t index)
 {
-    RawRec<U16> r;
-    if (U16) { r.a = ld_stream(recs + index); r.b = r.a; }
-    else { r.a = ld_stream(recs + index * 2); r.b = ld_stream(recs + index * 2 + 1); }
+    RawRec<LAY> r;
+    if constexpr (LAY == AMPLI_RECORDS_U24) {
+        const uint2 *__restrict__ q = (const uint2 *)((const char *)recs + index * 24);
+        r.a = q[0]; r.b = q[1]; r.c = q[2];
+    } else if constexpr (LAY == AMPLI_RECORDS_U16) {
+        r.a = ld_stream(recs + index); r.b = r.a;
+    } else {
+        r.a = ld_stream(recs + index * 2); r.b = ld_stream(recs + index * 2 + 1);
+    }
     return r;
 }
-template <bool U16> __device__ __forceinline__ void rec_decode(const RawRec<U16> &r, int4 &fw, int4 &bw)
+
+// four 24-bit fields out of three dwords
+__device__ __forceinline__ int4 unpack24(const unsigned w0, const unsigned w1, const unsigned w2)
 {
-    if (U16) {
+    return make_int4((int)(w0 & 0xFFFFFFu), (int)(__builtin_amdgcn_alignbit(w1, w0, 24) & 0xFFFFFFu),
+                     (int)(__builtin_amdgcn_alignbit(w2, w1, 16) & 0xFFFFFFu), (int)(w2 >> 8));
+}
+
+template <int LAY> __device__ __forceinline__ void rec_decode(const RawRec<LAY> &r, int4 &fw, int4 &bw)
+{
+    if constexpr (LAY == AMPLI_RECORDS_U24) {
+        fw = unpack24(r.a.x, r.a.y, r.b.x);
+        bw = unpack24(r.b.y, r.c.x, r.c.y);
+        if (fw.x == 0xFFFFFF) fw.x = AMPLI_ABSENT;
+    } else if constexpr (LAY == AMPLI_RECORDS_U16) {
         fw = make_int4(r.a.x & 0xFFFF, (int)((unsigned)r.a.x >> 16), r.a.y & 0xFFFF, (int)((unsigned)r.a.y >> 16));
         bw = make_int4(r.a.z & 0xFFFF, (int)((unsigned)r.a.z >> 16), r.a.w & 0xFFFF, (int)((unsigned)r.a.w >> 16));
         if (fw.x == 0xFFFF) fw.x = AMPLI_ABSENT;
@@ -856,7 +880,7 @@ __device__ __forceinline__ void lane_acc_shfl_down(const LaneAcc &a, LaneAcc &b,
 // workgroup (tile, split) owns chunk ((split*4 + w)*G + g)).  More, shorter waves for the same panel: the launch
 // then runs several balanced rounds instead of one and a half long ones (the fixed ~24 us of ramp + tail measured
 // at G = 1 shrinks with the wave lifetime).  A lane group still reads >= 512 contiguous bytes per sample row.
-template <bool FAST, int G, bool U16>
+template <bool FAST, int G, int LAY>
 __global__ __launch_bounds__(256) void error_reduce_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
@@ -889,28 +913,28 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     // (chunk_len) is wave-uniform and rows past a group's chunk are loaded clamped and not visited
     const size_t row_stride = (size_t)R; // in records
     size_t qi = (size_t)min(s0, S - 1) * R + p;
-    RawRec<U16> nx = rec_load<U16>(recs, qi);
+    RawRec<LAY> nx = rec_load<LAY>(recs, qi);
     for (int i = 0; i < chunk_len; ++i) {
         const int s = s0 + i;
         int4 c0, c1;
-        rec_decode<U16>(nx, c0, c1);
+        rec_decode<LAY>(nx, c0, c1);
         if (i + 1 < chunk_len) { // prefetch while this row is consumed
             if (s + 1 < S) qi += row_stride;
-            nx = rec_load<U16>(recs, qi);
+            nx = rec_load<LAY>(recs, qi);
         }
         if (s < s1) {
             // G == 1: s0 / s1 are wave-uniform, the whole wave is here -> the lean Germ_Max path.  Only the 16-byte
-            // layout is VALU-bound enough to profit; with 32-byte records the extra registers cost a wave of occupancy
-            if (FAST) visit_fast<G == 1 && U16>(f, c0, c1, first_sample + s, C, cov);
+            // and 24-byte layouts are VALU-bound enough to profit; with 32-byte records the extra registers cost a wave of occupancy
+            if (FAST) visit_fast<G == 1 && LAY != AMPLI_RECORDS_I32>(f, c0, c1, first_sample + s, C, cov);
             else visit_record(a, c0, c1, first_sample + s, C, cov);
             if (any_dup) { // extras of this position in the same sample, in file order
                 for (unsigned e = e0; e < e1; ++e) {
                     int4 x0, x1;
-                    rec_decode<U16>(rec_load<U16>(recs, (size_t)s * R + (size_t)P + e), x0, x1);
+                    rec_decode<LAY>(rec_load<LAY>(recs, (size_t)s * R + (size_t)P + e), x0, x1);
                     if (FAST) visit_fast<false>(f, x0, x1, first_sample + s, C, cov); // per-lane trip counts: no wave-level shortcuts
                     else visit_record(a, x0, x1, first_sample + s, C, cov);
                 }
-                if (FAST && G == 1 && U16) { // the extras may have given lanes their first record
+                if (FAST && G == 1 && LAY != AMPLI_RECORDS_I32) { // the extras may have given lanes their first record
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) f.zmask[nt] = __builtin_amdgcn_ballot_w64(f.gn[nt] == 0);
                 }
@@ -1206,7 +1230,7 @@ __device__ __forceinline__ long long call_slot(unsigned long long *__restrict__ 
 
 constexpr int PC_SAMPLES = 4;
 
-template <int MODE, bool U16>
+template <int MODE, int LAY>
 __global__ __launch_bounds__(256) void poisson_call_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
@@ -1230,7 +1254,7 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
         if (t >= T) break;
         const size_t o = (size_t)t * R + r;
         int4 r0, r1;
-        rec_decode<U16>(rec_load<U16>(recs, o), r0, r1);
+        rec_decode<LAY>(rec_load<LAY>(recs, o), r0, r1);
         const bool present = r0.x != AMPLI_ABSENT;
         const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
         const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
@@ -1316,7 +1340,7 @@ struct PcItem { // 32 bytes, self-contained: the drain kernel needs no second lo
     float e_fw, e_bw;           // effective errors (ampli_effective_err)
 };
 
-template <bool U16>
+template <int LAY>
 __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const int rows_per_block, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code,
@@ -1369,13 +1393,13 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS; // workgroups dealt round-robin
 
     size_t ri = (size_t)t0 * R + r; // record index
-    RawRec<U16> nx = rec_load<U16>(recs, ri);
+    RawRec<LAY> nx = rec_load<LAY>(recs, ri);
     for (int dt = 0; dt < nt_rows; ++dt) {
         int4 r0v, r1v;
-        rec_decode<U16>(nx, r0v, r1v);
+        rec_decode<LAY>(nx, r0v, r1v);
         if (dt + 1 < nt_rows) { // prefetch the next sample row
             ri += (size_t)R;
-            nx = rec_load<U16>(recs, ri);
+            nx = rec_load<LAY>(recs, ri);
         }
         const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
         const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
@@ -1544,6 +1568,33 @@ __global__ __launch_bounds__(256) void records_pack16_kernel(const int4 *__restr
                         (v[6] & 0xFFFFu) | (v[7] << 16));
 }
 
+// 8 x int32 records -> 8 x 24-bit records (AMPLI_ABSENT -> 0xFFFFFF); *overflow is raised for a count above 2^24 - 2
+__global__ __launch_bounds__(256) void records_pack24_kernel(const int4 *__restrict__ in, const long long n, uint2 *__restrict__ out,
+                                                             int *__restrict__ overflow)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 a = in[i * 2], b = in[i * 2 + 1];
+    const bool absent = a.x == AMPLI_ABSENT;
+    const unsigned v[8] = {absent ? 0xFFFFFFu : (unsigned)a.x, (unsigned)a.y, (unsigned)a.z, (unsigned)a.w,
+                           (unsigned)b.x, (unsigned)b.y, (unsigned)b.z, (unsigned)b.w};
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= (j == 0 && absent) ? false : v[j] > 0xFFFFFEu;
+    if (bad) atomicOr(overflow, 1);
+    unsigned w[6];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { // four 24-bit fields -> three dwords
+        const unsigned f0 = v[4 * h] & 0xFFFFFFu, f1 = v[4 * h + 1] & 0xFFFFFFu, f2 = v[4 * h + 2] & 0xFFFFFFu, f3 = v[4 * h + 3] & 0xFFFFFFu;
+        w[3 * h] = f0 | (f1 << 24);
+        w[3 * h + 1] = (f1 >> 8) | (f2 << 16);
+        w[3 * h + 2] = (f2 >> 16) | (f3 << 8);
+    }
+    out[i * 3] = make_uint2(w[0], w[1]);
+    out[i * 3 + 1] = make_uint2(w[2], w[3]);
+    out[i * 3 + 2] = make_uint2(w[4], w[5]);
+}
+
 __global__ void synth_ref_kernel(unsigned char *ref, const long long P, const unsigned long long seed)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1609,7 +1660,8 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
     if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate && !fin.slice_len) || (fin.packed && !d_acc))
         return fail(ctx, AMPLI_E_INVALID, "error_reduce: bad argument (P,S>0, cov>=1, table bound with ampli_acc_bind for the same P)");
     if (E > 0 && !d_dup_off) return fail(ctx, AMPLI_E_INVALID, "error_reduce: E > 0 needs dup_off");
-    if (((uintptr_t)d_recs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned");
+    if (((uintptr_t)d_recs & (ctx->rec_layout == AMPLI_RECORDS_U24 ? 7 : 15)) != 0)
+        return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // lane groups per wave: only for panels too small to fill the chip with 64-position waves (measured on c3:
@@ -1661,8 +1713,9 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
                        off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin)
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                           \
     do {                                                         \
-        if (ctx->rec_u16) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, true); \
-        else AMPLI_LAUNCH_REDUCE_L(FASTV, GV, false);            \
+        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U24);      \
+        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U16); \
+        else AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_I32);                                           \
     } while (0)
     if (fast) {
         if (G == 4) AMPLI_LAUNCH_REDUCE(true, 4);
@@ -1905,7 +1958,8 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
     if (d_q && mode != AMPLI_POISSON_FULL) return fail(ctx, AMPLI_E_INVALID, "poisson_call: dense q needs AMPLI_POISSON_FULL");
     if (d_calls && (!d_n_calls || capacity < AMPLI_CALL_SHARDS)) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call list needs n_calls and capacity >= AMPLI_CALL_SHARDS");
     if (d_n_calls && !d_calls) capacity = 0;
-    if (((uintptr_t)d_trecs & 15) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned");
+    if (((uintptr_t)d_trecs & (ctx->rec_layout == AMPLI_RECORDS_U24 ? 7 : 15)) != 0)
+        return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
     if (P + E >= (1ll << 30)) return fail(ctx, AMPLI_E_RANGE, "poisson_call: P + E must be below 2^30 records per sample");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rcj = join_drain(ctx); if (rcj) return rcj; } // the queue, its counters and the call list are about to be reused
@@ -1918,11 +1972,13 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
                        (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls, (long long)capacity, \
                        d_n_calls, d_q, d_af)
     if (mode == AMPLI_POISSON_FULL) {
-        if (ctx->rec_u16) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, true);
-        else AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, false);
+        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U24);
+        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U16);
+        else AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_I32);
     } else if (d_af) { // dense VAFs are a validation output: literal per-lane kernel
-        if (ctx->rec_u16) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, true);
-        else AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, false);
+        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U24);
+        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U16);
+        else AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_I32);
     } else {
         // tumour rows per workgroup: short workgroups win (measured on config 3: 4-6 rows 0.091 ms, 20 rows 0.098 ms,
         // 96 rows 0.167 ms -- many small workgroups keep every CU fed through the tail); thresholds are re-read per
@@ -1967,14 +2023,14 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         else
             ctx->queue_parity ^= 1;
         dim3 qgrid((unsigned)tiles, (unsigned)gy);
-        if (ctx->rec_u16)
-            hipLaunchKernelGGL(poisson_stream_kernel<true>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,
-                               (long long)E, d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
-                               (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
-        else
-            hipLaunchKernelGGL(poisson_stream_kernel<false>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,
-                               (long long)E, d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,
-                               (unsigned *)d_call_mask, ctx->d_flags, d_n_calls);
+#define AMPLI_LAUNCH_STREAM(LV)                                                                                                  \
+    hipLaunchKernelGGL(poisson_stream_kernel<LV>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,          \
+                       (long long)E, d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,         \
+                       (unsigned *)d_call_mask, ctx->d_flags, d_n_calls)
+        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
+        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
+        else AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_I32);
+#undef AMPLI_LAUNCH_STREAM
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;
         hipStream_t dstream = ctx->stream;
@@ -2031,6 +2087,17 @@ extern "C" int ampli_records_pack16(ampli_ctx *ctx, const int32_t *d_recs32, int
     hipLaunchKernelGGL(records_pack16_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, (const int4 *)d_recs32,
                        (long long)n_records, (uint4 *)d_recs16, d_overflow);
     return check_launch(ctx, "records_pack16_kernel");
+}
+
+extern "C" int ampli_records_pack24(ampli_ctx *ctx, const int32_t *d_recs32, int64_t n_records, void *d_recs24, int32_t *d_overflow)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_recs32 || !d_recs24 || !d_overflow || n_records <= 0 || ((uintptr_t)d_recs32 & 15) || ((uintptr_t)d_recs24 & 7))
+        return fail(ctx, AMPLI_E_INVALID, "records_pack24: bad argument (aligned buffers, n_records > 0, overflow word)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(records_pack24_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, (const int4 *)d_recs32,
+                       (long long)n_records, (uint2 *)d_recs24, d_overflow);
+    return check_launch(ctx, "records_pack24_kernel");
 }
 
 extern "C" int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t seed)

@@ -50,11 +50,11 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=1, help="N = 1 only: independent batches round-robin over this many HIP streams "
                     "(cross-batch overlap; per-kernel times then include contention, so the default stays 1)")
     ap.add_argument("--async-drain", action="store_true", help="poisson_call's drain kernel on a side stream (measured: no gain on config 3)")
-    ap.add_argument("--records", default="i32", choices=["auto", "i32", "u16"],
-                    help="record layout resident in HBM: i32 = 8 x int32 per record (default; SURVEY.md 8d's 32 B accounting), "
-                         "u16 = 8 x uint16 (half the bytes; every count must be <= 65534; packed once at setup with "
-                         "ampli_records_pack16), auto = u16 when the cohort fits.  At N = 1 the other layout is timed as well, "
-                         "outside the timed region, and reported beside the headline")
+    ap.add_argument("--records", default="auto", choices=["auto", "i32", "u24", "u16"],
+                    help="record layout resident in HBM (identical results): i32 = 8 x int32 = 32 B per record; u24 = 8 x 24 bits = "
+                         "24 B (counts <= 2^24 - 2, i.e. everything the fast kernels accept); u16 = 8 x uint16 = 16 B (counts <= 65534). "
+                         "auto (default) = u24 when the cohort fits, else i32.  The cohort is packed once at setup "
+                         "(ampli_records_pack24/16); at N = 1 the other layouts are timed too, outside the timed region")
     ap.add_argument("--merge", default="sliced", choices=["sliced", "allreduce"],
                     help="N>1 exchange: sliced = reduce-scatter + all-to-all + all-gather by position slices (default); "
                          "allreduce = one packed all-reduce + all-gather of whole germ-max regions")
@@ -197,27 +197,26 @@ def main():
     tumours = ctx.synth_fill(P, T, first_sample=rank * T, seed=SEED, depth=depth, tumour=True)
     ref_code = ctx.synth_ref(P, seed=SEED)
     # record layout: a resident cohort is packed ONCE (data preparation, like the H2D copy it replaces) and then
-    # evaluated many times; identical results either way (tests/test_gpu_u16.py)
-    u16 = False
-    alt_normals = alt_tumours = None  # the same records in the other layout, for the N = 1 comparison leg
-    n16, ok_n = ctx.pack16(normals)
-    t16, ok_t = ctx.pack16(tumours)
-    fits = torch.tensor([1 if (ok_n and ok_t) else 0], dtype=torch.int32, device=ctx.device)
-    if world > 1:
-        dist.all_reduce(fits, op=dist.ReduceOp.MIN)  # one layout for the whole job
-    fits = bool(int(fits.item()))
-    if args.records == "u16" and not fits:
-        raise SystemExit("--records u16: a count of this workload exceeds 65534")
-    if args.records != "i32" and fits:
-        u16, alt_normals, alt_tumours = True, normals, tumours
-        normals, tumours = n16, t16
-        ctx.set_record_layout(True)
-    elif fits:
-        alt_normals, alt_tumours = n16, t16
-    del n16, t16
-    if world > 1:
-        alt_normals = alt_tumours = None
-    rec_bytes = 16 if u16 else 32
+    # evaluated many times; identical results in every layout (tests/test_gpu_u16.py)
+    REC_BYTES = {"i32": 32, "u24": 24, "u16": 16}
+    packed = {"i32": (normals, tumours)}
+    for name in ("u24", "u16"):
+        pn, ok_n = ctx.pack(normals, name)
+        pt, ok_t = ctx.pack(tumours, name)
+        fits = torch.tensor([1 if (ok_n and ok_t) else 0], dtype=torch.int32, device=ctx.device)
+        if world > 1:
+            dist.all_reduce(fits, op=dist.ReduceOp.MIN)  # one layout for the whole job
+        if int(fits.item()):
+            packed[name] = (pn, pt)
+        del pn, pt
+    layout = args.records if args.records != "auto" else ("u24" if "u24" in packed else "i32")
+    if layout not in packed:
+        raise SystemExit(f"--records {layout}: a count of this workload does not fit that layout")
+    normals, tumours = packed[layout]
+    ctx.set_record_layout(layout)
+    if world > 1 or args.streams > 1:
+        packed = {layout: packed[layout]}  # the other layouts are only kept for the N = 1 comparison legs
+    rec_bytes = REC_BYTES[layout]
     accs = [ctx.new_acc(P) for _ in range(2 if world > 1 else 1)]
     for a in accs:
         a.buf.zero_()
@@ -343,7 +342,7 @@ def main():
             st = torch.cuda.Stream(device=dev_index)
             with torch.cuda.stream(st):
                 c = Context(dev_index)
-                c.set_record_layout(u16)
+                c.set_record_layout(layout)
                 f = c.error_estimate(normals, P, 0.002, 100)
                 r = c.poisson_call(tumours, P, f.thr, ref_code, 100, mode=mode, capacity=cap)
             lanes.append((c, f, r))
@@ -381,8 +380,7 @@ def main():
     if world > 1 and args.check:
         # every shard regenerated locally and reduced in one pass must equal the merged table, bit for bit
         allrecs = torch.cat([ctx.synth_fill(P, S, first_sample=k * S, seed=SEED, depth=depth) for k in range(world)])
-        if u16:
-            allrecs, _ = ctx.pack16(allrecs)
+        allrecs, _ = ctx.pack(allrecs, layout)
         ref = ctx.error_estimate(allrecs, P, 0.002, 100)
         got = fins[(args.warmup - 1) & 1]
         present = ref.germ_present > 0
@@ -432,13 +430,14 @@ def main():
     if flags != 0:
         raise SystemExit("error_finalize reported an exactness-envelope violation")
 
-    other = None
-    if world == 1 and alt_normals is not None and lanes is None:
-        # the same workload in the OTHER record layout, outside the timed region, for comparison
+    others = []
+    for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and world == 1 and lanes is None]:
+        # the same workload in the other record layouts, outside the timed region, for comparison
+        an, at = packed[name]
         c2 = Context(dev_index)
-        c2.set_record_layout(not u16)
-        f2 = c2.error_estimate(alt_normals, P, 0.002, 100)
-        r2 = c2.poisson_call(alt_tumours, P, f2.thr, ref_code, 100, mode=mode, capacity=cap)
+        c2.set_record_layout(name)
+        f2 = c2.error_estimate(an, P, 0.002, 100)
+        r2 = c2.poisson_call(at, P, f2.thr, ref_code, 100, mode=mode, capacity=cap)
         same = all(torch.equal(getattr(f2, k).view(torch.uint8), getattr(fin, k).view(torch.uint8)) for k in ("rate", "thr", "code", "germ_present"))
         same = same and torch.equal(r2["call_mask"], call_mask)
 
@@ -452,19 +451,19 @@ def main():
             return c2.elapsed_ms(a, b) / reps
 
         def step2():
-            c2.error_estimate(alt_normals, P, 0.002, 100, out=f2)
-            c2.poisson_call(alt_tumours, P, f2.thr, ref_code, 100, mode=mode, call_mask=r2["call_mask"], capacity=cap,
+            c2.error_estimate(an, P, 0.002, 100, out=f2)
+            c2.poisson_call(at, P, f2.thr, ref_code, 100, mode=mode, call_mask=r2["call_mask"], capacity=cap,
                             calls_buf=r2["calls_buf"], n_calls=r2["n_calls"])
 
-        ob = 32 if u16 else 16
-        t2_red = avg_ms(lambda: c2.error_estimate(alt_normals, P, 0.002, 100, out=f2), 20)
+        ob = REC_BYTES[name]
+        t2_red = avg_ms(lambda: c2.error_estimate(an, P, 0.002, 100, out=f2), 20)
         t2_step = avg_ms(step2, 20)
-        other = {"records": "i32 (32 B per record)" if u16 else "u16 (8 x uint16 = 16 B per record; every count <= 65534, packed once with ampli_records_pack16)",
-                 "ms_per_step": t2_step, "value": (P * S + P * T) / (t2_step * 1e-3), "error_reduce_ms": t2_red,
-                 "error_reduce_GBs": (ob * P * S + 88 * P) / (t2_red * 1e-3) / 1e9,
-                 "error_reduce_frac_of_peak": (ob * P * S + 88 * P) / (t2_red * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "same_outputs": bool(same), "note": "20 passes, HIP events, outside the timed region"}
+        others.append({"records": f"{name} ({ob} B per record)", "ms_per_step": t2_step, "value": (P * S + P * T) / (t2_step * 1e-3),
+                       "error_reduce_ms": t2_red, "error_reduce_GBs": (ob * P * S + 88 * P) / (t2_red * 1e-3) / 1e9,
+                       "error_reduce_frac_of_peak": (ob * P * S + 88 * P) / (t2_red * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "same_outputs": bool(same), "note": "20 passes, HIP events, outside the timed region"})
         c2.close()
+        del an, at, f2, r2
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -475,7 +474,7 @@ def main():
         # (N > 1, sliced merge: 21 doubles + 8 floats per position into the exchange buffers = 200 B)
         red_bytes = rec_bytes * P * S + ((200 * P if sliced else acc_bytes) if world > 1 else 88 * P)
         call_bytes = rec_bytes * P * T + 33 * P + P * T    # poisson_call: records + thresholds/ref + mask
-        lay = "true" if u16 else "false"
+        lay = {"i32": 0, "u16": 1, "u24": 2}[layout]
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = f"error_reduce_kernel<true, 1, {lay}>", t_red, red_bytes
         else:
@@ -504,13 +503,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("uint16 counts" if u16 else "int32 counts") + "; f64 sums / Poisson; f32 rates",
+            "dtype": {"i32": "int32", "u24": "24-bit", "u16": "uint16"}[layout] + " counts; f64 sums / Poisson; f32 rates",
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "depth": depth,
                        "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if world == 1 else 1,
                        "parallelism": f"tumour+normal sample shards x{world}" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table; three batches in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if world > 1 else ""),
                        "merge": (args.merge if world > 1 else None),
-                       "records": "u16 (8 x uint16 = 16 B per record)" if u16 else "i32 (8 x int32 = 32 B per record)"},
+                       "records": f"{layout} ({rec_bytes} B per record: 8 fields x {rec_bytes // 8 * 8} bits)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
                          "traffic_source": "profiles/r01/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 read correction)" if traffic else None},
@@ -521,8 +520,8 @@ def main():
                         "R_EE_positions_per_s": P / (t_red * 1e-3), "R_VC_evals_per_s": P * T / (t_call * 1e-3)},
             "calls_per_step": n_found,
         }
-        if other is not None:
-            out["other_record_layout"] = other
+        if others:
+            out["other_record_layouts"] = others
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)

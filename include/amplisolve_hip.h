@@ -48,10 +48,15 @@ extern "C" {
 
 #define AMPLI_ABI_VERSION 1
 #define AMPLI_ABSENT INT32_MIN
-/* record layouts: the default, and a compact one for cohorts whose every count is <= 65534 (half the HBM bytes):
- *   uint16 recs[n_samples][R][8], same field order, absent record: recs[..][0] == 0xFFFF */
+/* record layouts, same field order in all of them:
+ *   AMPLI_RECORDS_I32  int32 recs[n_samples][R][8], 32 B per record, absent: recs[..][0] == INT32_MIN
+ *   AMPLI_RECORDS_U24  8 x 24-bit little-endian fields, 24 B per record, absent: field 0 == 0xFFFFFF; for counts
+ *                      <= 2^24 - 2, which is every count the fast kernels accept anyway (a quarter fewer HBM bytes)
+ *   AMPLI_RECORDS_U16  uint16 recs[n_samples][R][8], 16 B per record, absent: recs[..][0] == 0xFFFF; for cohorts
+ *                      whose every count is <= 65534 (half the HBM bytes) */
 #define AMPLI_RECORDS_I32 0
 #define AMPLI_RECORDS_U16 1
+#define AMPLI_RECORDS_U24 2
 
 #define AMPLI_OK 0
 #define AMPLI_E_INVALID (-1)  /* bad argument */
@@ -78,6 +83,8 @@ int ampli_set_record_layout(ampli_ctx *ctx, int32_t layout);
 /* device-side conversion 8 x int32 -> 8 x uint16 of n_records records; *d_overflow is OR-ed with 1 when a count does
  * not fit (the caller then stays with AMPLI_RECORDS_I32) */
 int ampli_records_pack16(ampli_ctx *ctx, const int32_t *d_recs32, int64_t n_records, void *d_recs16, int32_t *d_overflow);
+/* the same for the 24-byte layout (8 x 24 bits); overflow: a count above 2^24 - 2 */
+int ampli_records_pack24(ampli_ctx *ctx, const int32_t *d_recs32, int64_t n_records, void *d_recs24, int32_t *d_overflow);
 void ampli_ctx_destroy(ampli_ctx *ctx);
 const char *ampli_last_error(ampli_ctx *ctx);
 int ampli_sync(ampli_ctx *ctx);        /* hipStreamSynchronize */

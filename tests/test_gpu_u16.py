@@ -1,5 +1,5 @@
-"""The compact record layout (AMPLI_RECORDS_U16: 8 x uint16 per record, half the HBM bytes) gives the same results
-as the oracle on the same records, through every kernel that reads records."""
+"""The compact record layouts (AMPLI_RECORDS_U16: 8 x uint16 = 16 B per record; AMPLI_RECORDS_U24: 8 x 24 bits = 24 B)
+give the same results as the oracle on the same records, through every kernel that reads records."""
 import numpy as np
 import pytest
 
@@ -10,8 +10,9 @@ from tests.test_gpu_parity import _t, assert_acc_equal, assert_final_equal
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx16():
+@pytest.fixture(scope="module", params=["u16", "u24"])
+def ctx16(request):
+    """A context on one of the compact layouts (the name dates from the first of them)."""
     import torch
 
     if not torch.cuda.is_available():
@@ -19,28 +20,41 @@ def ctx16():
     from amplisolve_amd import Context
 
     c = Context(0)
-    c.set_record_layout(True)
+    c.set_record_layout(request.param)
+    c.layout_name = request.param
     yield c
     c.close()
 
 
+def host_pack(recs, layout):
+    """numpy twin of ampli_records_pack16 / ampli_records_pack24"""
+    absent = recs[..., 0] == np.iinfo(np.int32).min
+    v = recs.astype(np.int64)
+    if layout == "u16":
+        v[absent, 0] = 0xFFFF
+        return v.astype(np.uint16).view(np.uint8).reshape(recs.shape[:-1] + (16,))
+    v[absent, 0] = 0xFFFFFF
+    b = np.stack([(v >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.uint8)  # [..., 8 fields, 3 bytes] little-endian
+    return b.reshape(recs.shape[:-1] + (24,))
+
+
 def to16(ctx16, recs):
-    """int32 numpy records -> int16 device records through ampli_records_pack16 (and cross-checked on the host)."""
-    r16, fits = ctx16.pack16(_t(recs))
+    """int32 numpy records -> device records in the context's layout through ampli_records_pack16/24, cross-checked
+    against the host packing."""
+    packed, fits = ctx16.pack(_t(recs), ctx16.layout_name)
     assert fits
-    host = recs.astype(np.int64)
-    host[recs[..., 0] == np.iinfo(np.int32).min, 0] = 0xFFFF
-    assert np.array_equal(r16.cpu().numpy().view(np.uint16), host.astype(np.uint16))
-    return r16
+    assert np.array_equal(packed.cpu().numpy().view(np.uint8).reshape(recs.shape[:-1] + (-1,)), host_pack(recs, ctx16.layout_name))
+    return packed
 
 
-def test_pack16_flags_counts_that_do_not_fit(ctx16):
+def test_pack_flags_counts_that_do_not_fit(ctx16):
+    top = 65534 if ctx16.layout_name == "u16" else (1 << 24) - 2
     recs = synth_recs(100, 3)
-    recs[1, 7, 2] = 65534
-    _, fits = ctx16.pack16(_t(recs))
+    recs[1, 7, 2] = top
+    _, fits = ctx16.pack(_t(recs), ctx16.layout_name)
     assert fits
-    recs[2, 50, 5] = 65535  # would collide with nothing, but the absent marker lives at this value in field 0: not allowed anywhere
-    _, fits = ctx16.pack16(_t(recs))
+    recs[2, 50, 5] = top + 1  # the absent marker lives at this value in field 0: not allowed anywhere
+    _, fits = ctx16.pack(_t(recs), ctx16.layout_name)
     assert not fits
 
 
@@ -142,14 +156,14 @@ def test_config3_full_size_u16_equals_i32(ctx, ctx16):
     tumours = ctx.synth_fill(P, T, first_sample=0, depth=2000, tumour=True)
     ref_code = ctx.synth_ref(P)
     a = ctx.error_estimate(normals, P)
-    n16, fits = ctx16.pack16(normals)
+    n16, fits = ctx16.pack(normals, ctx16.layout_name)
     assert fits
     b = ctx16.error_estimate(n16, P)
     for k in ("rate", "thr", "code", "germ_present"):
         assert torch.equal(getattr(a, k).view(torch.uint8), getattr(b, k).view(torch.uint8)), k
     m = a.germ_present > 0
     assert torch.equal(a.germ_val[m], b.germ_val[m])
-    t16, fits = ctx16.pack16(tumours)
+    t16, fits = ctx16.pack(tumours, ctx16.layout_name)
     assert fits
     ra = ctx.poisson_call(tumours, P, a.thr, ref_code, 100, capacity=1 << 20)
     rb = ctx16.poisson_call(t16, P, a.thr, ref_code, 100, capacity=1 << 20)
@@ -168,6 +182,9 @@ def test_error_reduce_u16_largest_depths(ctx16):
         recs[s_i, p_i] = [60000, 60000, 60000, t, 59000, 61000, 60500, t + 7]      # RD ~ 366 k, T allele at 0.3 - 3 %
     recs[1, 5] = [65534, 65534, 65534, 3000, 65534, 65534, 65534, 3100]             # RD = 399 304 in the second row of a chunk
     recs[S - 1, 5] = [2000, 3, 1, 60, 1900, 2, 0, 55]                               # a later, ordinary record must still compare right
+    if ctx16.layout_name == "u24":  # and depths of millions, still inside the fast kernel's 2^22 envelope
+        recs[3, 9] = [1_900_000, 80_000, 7, 0, 1_800_000, 75_000, 0, 9]
+        recs[7, 9] = [1_000_000, 30_000, 3, 1, 990_000, 29_000, 2, 0]
     ref = orc.error_reduce(recs, P, 0.002, 100)
     for general, groups in ((False, 1), (False, 2), (True, 1)):
         ctx16.set_tuning(0, general=general, groups=groups)

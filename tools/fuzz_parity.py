@@ -57,8 +57,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="replay one case by its printed seed")
     args = ap.parse_args()
-    c32, c16 = Context(0), Context(0)
-    c16.set_record_layout(True)
+    ctxs = {"i32": Context(0), "u16": Context(0), "u24": Context(0)}
+    for k, c in ctxs.items():
+        c.set_record_layout(k)
     t_end = time.time() + args.seconds
     n = {"reduce": 0, "sliced": 0, "poisson": 0}
     case = 0
@@ -80,17 +81,16 @@ def main():
                 mult[rng.random(P) < 0.01] = 2
             dup_off = np.concatenate([[0], np.cumsum(mult)]).astype(np.uint32)
             E = int(dup_off[-1])
-            u16 = bool(rng.random() < 0.5)
+            layout = str(rng.choice(["i32", "u16", "u24"]))
+            u16 = layout == "u16"
             kind = "synth" if rng.random() < 0.5 else "edge"
             recs = make_records(rng, P, E, S, kind, u16)
             C_value = float(rng.choice([0.002, 0.01, 0.0005, 0.05]))
             cov = int(rng.choice([1, 50, 100, 500, 1000]))
-            ctx = c16 if u16 else c32
-            dev = t(recs)
-            if u16:
-                dev, fits = ctx.pack16(dev)
-                if not fits:
-                    raise AssertionError("records do not fit uint16 although generated to")
+            ctx = ctxs[layout]
+            dev, fits = ctx.pack(t(recs), layout)
+            if not fits:
+                raise AssertionError("records do not fit the layout although generated to")
             d_dup = t(dup_off) if E else None
             o_acc = orc.error_reduce(recs, P, C_value, cov, E=E, dup_off=dup_off if E else None)
             o_fin = orc.error_finalize(o_acc)
@@ -144,10 +144,8 @@ def main():
             ref_code[rng.random(P) < 0.05] = 255
             ext_pos = np.repeat(np.arange(P), mult).astype(np.uint32)
             exp = orc.poisson_call(trecs, P, thr, ref_code, cov, E=E, ext_pos=ext_pos if E else None)
-            td = t(trecs)
-            if u16:
-                td, fits = ctx.pack16(td)
-                assert fits
+            td, fits = ctx.pack(t(trecs), layout)
+            assert fits
             for mode in (POISSON_PREFILTER, POISSON_FULL):
                 kw = dict(mode=mode, E=E, ext_pos=t(ext_pos) if E else None, dense_q=(mode == POISSON_FULL),
                           capacity=max(1 << 12, 32 * (P + E) * T * 4))
@@ -175,7 +173,7 @@ def main():
                     raise AssertionError(f"call list length, mode {mode}")
             n["poisson"] += 1
         except AssertionError as e:
-            print(f"MISMATCH in case seed={seed}: {e}  (P={P} S={S} E={E} u16={u16} kind={kind} C={C_value} cov={cov})", flush=True)
+            print(f"MISMATCH in case seed={seed}: {e}  (P={P} S={S} E={E} layout={layout} kind={kind} C={C_value} cov={cov})", flush=True)
             sys.exit(1)
         if case % 50 == 0:
             print(f"{case} cases ok {n}", flush=True)

@@ -6,14 +6,17 @@ from amplisolve_amd import Context
 
 P, S, T = 100_000, 256, 96
 torch.cuda.set_stream(torch.cuda.Stream())
-c32, c16 = Context(0), Context(0)
-c16.set_record_layout(True)
+c32, c16, c24 = Context(0), Context(0), Context(0)
+c16.set_record_layout("u16")
+c24.set_record_layout("u24")
 normals = c32.synth_fill(P, S, first_sample=0, seed=0xA3F15019, depth=2000)
 tumours = c32.synth_fill(P, T, first_sample=0, seed=0xA3F15019, depth=2000, tumour=True)
 ref_code = c32.synth_ref(P, seed=0xA3F15019)
 n16, ok1 = c16.pack16(normals)
 t16, ok2 = c16.pack16(tumours)
-assert ok1 and ok2
+n24, ok3 = c24.pack24(normals)
+t24, ok4 = c24.pack24(tumours)
+assert ok1 and ok2 and ok3 and ok4
 fin = {}
 res = {}
 
@@ -31,7 +34,7 @@ def timeit(ctx, fn, reps=40):
 
 
 for rnd in range(3):
-    for name, ctx, nr, tr in (("i32", c32, normals, tumours), ("u16", c16, n16, t16)):
+    for name, ctx, nr, tr in (("i32", c32, normals, tumours), ("u24", c24, n24, t24), ("u16", c16, n16, t16)):
         fin[name] = ctx.error_estimate(nr, P, 0.002, 100)
         res[name] = ctx.poisson_call(tr, P, fin[name].thr, ref_code, 100, capacity=1 << 20)
         f, r = fin[name], res[name]
@@ -45,5 +48,6 @@ for rnd in range(3):
         t_step = timeit(ctx, step)
         print(f"{name}: error_estimate {t_red:7.1f} us   poisson_call {t_call:7.1f} us   step {t_step:7.1f} us   "
               f"-> {(P * S + P * T) / (t_step * 1e-6):.3e} evaluations/s", flush=True)
-same = all(torch.equal(getattr(fin["i32"], k).view(torch.uint8), getattr(fin["u16"], k).view(torch.uint8)) for k in ("rate", "thr", "code", "germ_present"))
-print("tables identical:", same, " masks identical:", torch.equal(res["i32"]["call_mask"], res["u16"]["call_mask"]))
+for o in ("u16", "u24"):
+    same = all(torch.equal(getattr(fin["i32"], k).view(torch.uint8), getattr(fin[o], k).view(torch.uint8)) for k in ("rate", "thr", "code", "germ_present"))
+    print(o, "tables identical:", same, " masks identical:", torch.equal(res["i32"]["call_mask"], res[o]["call_mask"]))
