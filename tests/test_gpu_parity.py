@@ -672,7 +672,22 @@ def test_baseline_configs_4_and_5_full_size(ctx, name, P, S, T, depth):
     n = ctx.n_calls_total(res)
     bits = sum(int(((res["call_mask"] >> a) & 1).sum()) for a in range(4))
     assert n == bits > 0
-    del nor, tum, res, fin
+    # the packed 24-byte layout (what bench.py keeps resident) at the same full size: every output identical
+    from amplisolve_amd import Context
+
+    c24 = Context(0)
+    c24.set_record_layout("u24")
+    n24, fits_n = c24.pack24(nor)
+    t24, fits_t = c24.pack24(tum)
+    assert fits_n and fits_t
+    fin24 = c24.error_estimate(n24, P)
+    res24 = c24.poisson_call(t24, P, fin24.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 22)
+    assert c24.flags() == 0 and int(fin24.flags.item()) == 0
+    for k in ("rate", "thr", "code", "germ_present"):
+        assert torch.equal(getattr(fin, k).view(torch.uint8), getattr(fin24, k).view(torch.uint8)), k
+    assert torch.equal(res["call_mask"], res24["call_mask"]) and c24.n_calls_total(res24) == n
+    c24.close()
+    del nor, tum, res, fin, n24, t24, fin24, res24
     torch.cuda.empty_cache()
 
 
