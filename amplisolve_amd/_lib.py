@@ -74,6 +74,7 @@ HIP_SYMBOLS = {
     "ampli_gm_merge": (C.c_int, [vp, C.POINTER(AccTable), vp, i32]),
     "ampli_error_finalize": (C.c_int, [vp, C.POINTER(AccTable), f32, i32, vp, vp, vp, vp, vp, vp]),
     "ampli_poisson_call": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
+    "ampli_poisson_call_blocks": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
     "ampli_score_batch": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
     "ampli_roundtrip_batch": (C.c_int, [vp, vp, i64, vp]),
     "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),

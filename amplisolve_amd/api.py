@@ -325,7 +325,9 @@ class Context:
 
     def poisson_call(self, trecs, P: int, thr, ref_code, cov: int = 100, mode: int = POISSON_PREFILTER, E: int = 0,
                      ext_pos=None, call_mask=None, capacity: int = 0, dense_q: bool = False, dense_af: bool = False,
-                     calls_buf=None, n_calls=None):
+                     calls_buf=None, n_calls=None, blocks_of: int = 0):
+        """thr: float32 [2, 4, P] thresholds -- or, with blocks_of = n > 0, the all-gathered blocks of an n-slice
+        position-sliced merge (ampli_poisson_call_blocks: thresholds are read straight from the blocks)."""
         import torch
 
         assert trecs.dtype == self._rec_dtype() and trecs.is_cuda and trecs.is_contiguous()
@@ -343,8 +345,13 @@ class Context:
             capacity -= capacity % CALL_SHARDS
         if (capacity > 0 or n_calls is not None) and n_calls is None:
             n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=d)
-        self._check(self.lib.ampli_poisson_call(self.h, _ptr(trecs), P, E, _ptr(ext_pos), T, _ptr(thr), _ptr(ref_code), cov,
-                                                mode, _ptr(call_mask), _ptr(calls_buf), capacity, _ptr(n_calls), _ptr(q), _ptr(af)))
+        if blocks_of > 0:
+            self._check(self.lib.ampli_poisson_call_blocks(self.h, _ptr(trecs), P, E, _ptr(ext_pos), T, _ptr(thr), blocks_of,
+                                                           _ptr(ref_code), cov, mode, _ptr(call_mask), _ptr(calls_buf), capacity,
+                                                           _ptr(n_calls), _ptr(q), _ptr(af)))
+        else:
+            self._check(self.lib.ampli_poisson_call(self.h, _ptr(trecs), P, E, _ptr(ext_pos), T, _ptr(thr), _ptr(ref_code), cov,
+                                                    mode, _ptr(call_mask), _ptr(calls_buf), capacity, _ptr(n_calls), _ptr(q), _ptr(af)))
         return dict(call_mask=call_mask, q=q, af=af, calls_buf=calls_buf, n_calls=n_calls, capacity=capacity)
 
     @staticmethod

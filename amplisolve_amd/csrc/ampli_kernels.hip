@@ -635,46 +635,57 @@ __device__ __forceinline__ void lane_acc_store_gm(const AccPtrs &t, const long l
     }
 }
 
-__device__ __forceinline__ void finalize_lane(const LaneAcc &a, const long long P, const long long p, const float C,
-                                              const int cov, const FinOut &o)
+// one (position, nucleotide): returns true when a double sum left the exactness envelope
+__device__ __forceinline__ bool finalize_one(const int nt, const double sfw, const double sbw, const long long dfw, const long long dbw,
+                                             const int cnt, const int nrec, const int gm_n, const float gm_rest, const long long P,
+                                             const long long p, const double limit, const FinOut &o)
 {
-    // exactness envelope of the double sums: every addend is a multiple of ulp(float(cov)*C) and the
-    // running sum must stay below 2^52 such ulps
+    const long long i = nt * P + p, ifw = (0 * 4 + nt) * P + p, ibw = (1 * 4 + nt) * P + p;
+    float r_fw = 0.0f, r_bw = 0.0f;
+    unsigned char c;
+    if ((double)cnt < 0.338 * (double)nrec) { // EE:1659
+        c = 1;
+    } else {
+        r_fw = (float)sfw / (float)(double)dfw; // EE:1679
+        r_bw = (float)sbw / (float)(double)dbw; // EE:1680
+        if (isnan(r_fw) || isnan(r_bw)) { c = 2; r_fw = 0.0f; r_bw = 0.0f; } // EE:1682
+        else c = 0;
+    }
+    o.code[i] = c;
+    o.rate[ifw] = r_fw;
+    o.rate[ibw] = r_bw;
+    if (o.thr) {
+        o.thr[ifw] = c ? 0.01f : ampli_text_roundtrip(r_fw); // EE:2680-2684 / EE:1704 -> VC:889-890
+        o.thr[ibw] = c ? 0.01f : ampli_text_roundtrip(r_bw);
+    }
+    if (o.germ_val) {
+        float v = (nt == 0) ? -888.0f : 0.0f; // EE:1260 / EE:1318,1374,1431
+        if (gm_n > 1) { if (v <= gm_rest) v = gm_rest; }
+        o.germ_val[i] = gm_n ? v : 0.0f;
+        if (o.germ_present) o.germ_present[i] = gm_n ? 1 : 0;
+    }
+    return !(sfw < limit) || !(sbw < limit);
+}
+
+// exactness envelope of the double sums: every addend is a multiple of ulp(float(cov)*C) and the
+// running sum must stay below 2^52 such ulps
+__device__ __forceinline__ double envelope_limit(const float C, const int cov)
+{
     const float pmin = (float)cov * C;
     int ex;
     (void)frexpf(pmin > 0 ? pmin : 1.0f, &ex);
-    const double limit = ldexp(1.0, ex - 24) * 9007199254740992.0 * 0.5;
+    return ldexp(1.0, ex - 24) * 9007199254740992.0 * 0.5;
+}
+
+__device__ __forceinline__ void finalize_lane(const LaneAcc &a, const long long P, const long long p, const float C,
+                                              const int cov, const FinOut &o)
+{
+    const double limit = envelope_limit(C, cov);
     bool bad = false;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const long long i = nt * P + p, ifw = (0 * 4 + nt) * P + p, ibw = (1 * 4 + nt) * P + p;
-        const double sfw = a.snt[0][nt], sbw = a.snt[1][nt];
-        bad |= !(sfw < limit) || !(sbw < limit);
-        float r_fw = 0.0f, r_bw = 0.0f;
-        unsigned char c;
-        if ((double)a.cnt[nt] < 0.338 * (double)a.nrec) { // EE:1659
-            c = 1;
-        } else {
-            r_fw = (float)sfw / (float)(double)a.srd[0][nt]; // EE:1679
-            r_bw = (float)sbw / (float)(double)a.srd[1][nt]; // EE:1680
-            if (isnan(r_fw) || isnan(r_bw)) { c = 2; r_fw = 0.0f; r_bw = 0.0f; } // EE:1682
-            else c = 0;
-        }
-        o.code[i] = c;
-        o.rate[ifw] = r_fw;
-        o.rate[ibw] = r_bw;
-        if (o.thr) {
-            o.thr[ifw] = c ? 0.01f : ampli_text_roundtrip(r_fw); // EE:2680-2684 / EE:1704 -> VC:889-890
-            o.thr[ibw] = c ? 0.01f : ampli_text_roundtrip(r_bw);
-        }
-        if (o.germ_val) {
-            const int n = a.gm_n[nt];
-            float v = (nt == 0) ? -888.0f : 0.0f; // EE:1260 / EE:1318,1374,1431
-            if (n > 1) { const float r = a.gm_rest[nt]; if (v <= r) v = r; }
-            o.germ_val[i] = n ? v : 0.0f;
-            if (o.germ_present) o.germ_present[i] = n ? 1 : 0;
-        }
-    }
+    for (int nt = 0; nt < 4; ++nt)
+        bad |= finalize_one(nt, a.snt[0][nt], a.snt[1][nt], a.srd[0][nt], a.srd[1][nt], a.cnt[nt], a.nrec, a.gm_n[nt], a.gm_rest[nt], P, p,
+                            limit, o);
     if (bad && o.flags) atomicOr(o.flags, 1);
 }
 
@@ -1156,29 +1167,26 @@ __global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double 
                                                                    const int nparts, const long long L, const long long p0,
                                                                    const long long P, const float C, const int cov, char *blk)
 {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= L || p0 + q >= P) return;
-    LaneAcc a;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        a.snt[0][nt] = sums[(0 * 4 + nt) * L + q];
-        a.snt[1][nt] = sums[(1 * 4 + nt) * L + q];
-        a.srd[0][nt] = (long long)sums[(8 + 0 * 4 + nt) * L + q];
-        a.srd[1][nt] = (long long)sums[(8 + 1 * 4 + nt) * L + q];
-        a.cnt[nt] = (int)sums[(16 + nt) * L + q];
-        int n = 0;
-        float rest = -INFINITY;
-        for (int k = 0; k < nparts; ++k) { // L (+) R = (L.first, max(L.rest, R.first_af, R.rest)), shards in sample order
-            const float fa = gm[((size_t)k * 8 + nt) * L + q];
-            if (fa < 0.0f) continue; // shard without a qualifying record
-            const float rr = gm[((size_t)k * 8 + 4 + nt) * L + q];
-            if (n == 0) { rest = rr; n = (rr > -INFINITY) ? 2 : 1; }
-            else { if (rest <= fa) rest = fa; if (rest <= rr) rest = rr; n = 2; }
-        }
-        a.gm_n[nt] = n; a.gm_rest[nt] = rest; a.gm_first[nt] = 0; a.gm_first_af[nt] = 0.0f; // n: 0, 1 or "more than one"
+    // one thread per (nucleotide, position of the slice): the slice is short (P / n positions), so the launch is a
+    // latency chain -- four times the threads, a quarter of the chain
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nt = (int)(t / L);
+    const long long q = t - (long long)nt * L;
+    if (nt >= 4 || p0 + q >= P) return;
+    int n = 0;
+    float rest = -INFINITY;
+    for (int k = 0; k < nparts; ++k) { // L (+) R = (L.first, max(L.rest, R.first_af, R.rest)), shards in sample order
+        const float fa = gm[((size_t)k * 8 + nt) * L + q];
+        if (fa < 0.0f) continue; // shard without a qualifying record
+        const float rr = gm[((size_t)k * 8 + 4 + nt) * L + q];
+        if (n == 0) { rest = rr; n = (rr > -INFINITY) ? 2 : 1; } // n: 0, 1 or "more than one"
+        else { if (rest <= fa) rest = fa; if (rest <= rr) rest = rr; n = 2; }
     }
-    a.nrec = (int)sums[20 * L + q];
-    finalize_lane(a, L, q, C, cov, slice_block_view(blk, L));
+    const FinOut o = slice_block_view(blk, L);
+    const bool bad = finalize_one(nt, sums[(0 * 4 + nt) * L + q], sums[(1 * 4 + nt) * L + q], (long long)sums[(8 + 0 * 4 + nt) * L + q],
+                                  (long long)sums[(8 + 1 * 4 + nt) * L + q], (int)sums[(16 + nt) * L + q], (int)sums[20 * L + q], n, rest,
+                                  L, q, envelope_limit(C, cov), o);
+    if (bad) atomicOr(o.flags, 1);
 }
 
 __global__ __launch_bounds__(256) void error_table_unslice_kernel(const char *__restrict__ blocks, const int nparts, const long long L,
@@ -1230,10 +1238,21 @@ __device__ __forceinline__ long long call_slot(unsigned long long *__restrict__ 
 
 constexpr int PC_SAMPLES = 4;
 
+// threshold plane j (= strand*4 + nucleotide) of position p: plane-major [8][P] (slice_len == 0), or straight from the
+// all-gathered blocks of a position-sliced merge (block k = positions [k*slice_len, ...): rate 32L | thr 32L | ...)
+__device__ __forceinline__ float thr_at(const float *__restrict__ thr, const long long P, const long long slice_len,
+                                        const size_t block_bytes, const int j, const long long p)
+{
+    if (slice_len == 0) return thr[j * P + p];
+    const long long k = p / slice_len, q = p - k * slice_len;
+    return ((const float *)((const char *)thr + (size_t)k * block_bytes + (size_t)slice_len * 32))[j * slice_len + q];
+}
+
 template <int MODE, int LAY>
 __global__ __launch_bounds__(256) void poisson_call_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
-    const int T, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code, const int cov,
+    const int T, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
+    const unsigned char *__restrict__ ref_code, const int cov,
     unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
     unsigned long long *__restrict__ n_calls, double *__restrict__ qd, float *__restrict__ afd)
 {
@@ -1244,8 +1263,8 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
     float th[2][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        th[0][nt] = thr[(0 * 4 + nt) * P + p]; // VC:887-890
-        th[1][nt] = thr[(1 * 4 + nt) * P + p];
+        th[0][nt] = thr_at(thr, P, thr_L, thr_bb, 0 * 4 + nt, p); // VC:887-890
+        th[1][nt] = thr_at(thr, P, thr_L, thr_bb, 1 * 4 + nt, p);
     }
     const int ref = ref_code[p];
     const int t0 = blockIdx.y * PC_SAMPLES;
@@ -1343,7 +1362,8 @@ struct PcItem { // 32 bytes, self-contained: the drain kernel needs no second lo
 template <int LAY>
 __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
-    const int T, const int rows_per_block, const float *__restrict__ thr, const unsigned char *__restrict__ ref_code,
+    const int T, const int rows_per_block, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
+    const unsigned char *__restrict__ ref_code,
     const int cov, PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
     unsigned *__restrict__ mask_words, int *__restrict__ flags, unsigned long long *__restrict__ n_calls)
 {
@@ -1387,7 +1407,7 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            te[st][nt] = ampli_effective_err(thr[(st * 4 + nt) * P + p]); // VC:887-890
+            te[st][nt] = ampli_effective_err(thr_at(thr, P, thr_L, thr_bb, st * 4 + nt, p)); // VC:887-890
         }
     }
     const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS; // workgroups dealt round-robin
@@ -1847,7 +1867,7 @@ extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_s
         return fail(ctx, AMPLI_E_INVALID, "error_finalize_slice: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long L = ampli_slice_len(P, n_slices);
-    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, ctx->stream, d_sum_slice,
+    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((4 * L + 255) / 256)), dim3(256), 0, ctx->stream, d_sum_slice,
                        d_gm_recv, (int)n_slices, L, (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block);
     return check_launch(ctx, "error_finalize_slice_kernel");
 }
@@ -1945,10 +1965,10 @@ extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc
     return launch_finalize(ctx, to_ptrs(d_acc), P, C, (int)cov, fo);
 }
 
-extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
-                                  int32_t T, const float *d_thr, const uint8_t *d_ref_code, int32_t cov, int32_t mode,
-                                  uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
-                                  unsigned long long *d_n_calls, double *d_q, float *d_af)
+static int poisson_call_impl(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
+                             int32_t T, const float *d_thr, const long long thr_L, const size_t thr_bb, const uint8_t *d_ref_code,
+                             int32_t cov, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+                             unsigned long long *d_n_calls, double *d_q, float *d_af)
 {
     if (!ctx) return AMPLI_E_INVALID;
     if (!d_trecs || P <= 0 || E < 0 || T <= 0 || !d_thr || !d_ref_code || !d_call_mask || cov < 1)
@@ -1969,7 +1989,8 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         HIP_TRY(ctx, hipMemsetAsync(d_n_calls, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
 #define AMPLI_LAUNCH_PC(MODEV, UV)                                                                                              \
     hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,  \
-                       (long long)E, d_ext_pos, (int)T, d_thr, d_ref_code, (int)cov, d_call_mask, d_calls, (long long)capacity, \
+                       (long long)E, d_ext_pos, (int)T, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, d_call_mask, d_calls,       \
+                       (long long)capacity,                                                                                     \
                        d_n_calls, d_q, d_af)
     if (mode == AMPLI_POISSON_FULL) {
         if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U24);
@@ -2025,7 +2046,8 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         dim3 qgrid((unsigned)tiles, (unsigned)gy);
 #define AMPLI_LAUNCH_STREAM(LV)                                                                                                  \
     hipLaunchKernelGGL(poisson_stream_kernel<LV>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,          \
-                       (long long)E, d_ext_pos, (int)T, rows, d_thr, d_ref_code, (int)cov, (PcItem *)ctx->queue, per, qn,         \
+                       (long long)E, d_ext_pos, (int)T, rows, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, (PcItem *)ctx->queue,   \
+                       per, qn,                                                                                                   \
                        (unsigned *)d_call_mask, ctx->d_flags, d_n_calls)
         if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
         else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
@@ -2048,6 +2070,27 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
         return check_launch(ctx, "poisson_drain_kernel");
     }
     return check_launch(ctx, "poisson_call_kernel");
+}
+
+extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
+                                  int32_t T, const float *d_thr, const uint8_t *d_ref_code, int32_t cov, int32_t mode,
+                                  uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+                                  unsigned long long *d_n_calls, double *d_q, float *d_af)
+{
+    return poisson_call_impl(ctx, d_trecs, P, E, d_ext_pos, T, d_thr, 0, 0, d_ref_code, cov, mode, d_call_mask, d_calls, capacity,
+                             d_n_calls, d_q, d_af);
+}
+
+extern "C" int ampli_poisson_call_blocks(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
+                                         int32_t T, const void *d_blocks, int32_t n_slices, const uint8_t *d_ref_code, int32_t cov,
+                                         int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+                                         unsigned long long *d_n_calls, double *d_q, float *d_af)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (n_slices < 1 || P <= 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call_blocks: bad argument");
+    const long long L = ampli_slice_len(P, n_slices);
+    return poisson_call_impl(ctx, d_trecs, P, E, d_ext_pos, T, (const float *)d_blocks, L, slice_block_bytes(L), d_ref_code, cov, mode,
+                             d_call_mask, d_calls, capacity, d_n_calls, d_q, d_af);
 }
 
 extern "C" int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err, int64_t n,

@@ -248,6 +248,8 @@ def main():
     if args.async_drain:
         ctx.set_async_drain(True)
 
+    last_blocks = [None]
+
     def reduce_part(i, timed, slot):
         nonlocal fin
         timed = timed and i % max(1, args.event_every) == 0
@@ -265,8 +267,17 @@ def main():
     def call_part(i, timed, slot):
         nonlocal fin
         timed = timed and i % max(1, args.event_every) == 0
-        if sliced:  # the gathered blocks of every rank's slice -> the plane-major error table
-            fins[i & 1] = fin = ctx.error_table_unslice(P, world, merger.blocks[slot], out=fins[i & 1])
+        if sliced:
+            # poisson_call reads the thresholds straight from the gathered blocks (the blocks ARE the error table, by
+            # position slice); the plane-major form is only materialised where somebody wants it (--check, the flags)
+            if timed:
+                ctx.record(ev[i][2])
+            ctx.poisson_call(tumours, P, merger.blocks[slot], ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
+                             calls_buf=calls_buf, n_calls=n_calls, blocks_of=world)
+            if timed:
+                ctx.record(ev[i][3])
+            last_blocks[0] = merger.blocks[slot]
+            return
         elif world > 1:  # finalize straight from the all-reduced sums + gathered germ-max regions
             fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
         if timed:
@@ -377,6 +388,14 @@ def main():
         merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack)
         run_steps(args.warmup, False)
         fence()
+    def materialise():
+        """sliced merge: the plane-major table of the last finished batch (outside the per-batch work)"""
+        nonlocal fin
+        if sliced and last_blocks[0] is not None:
+            fin = ctx.error_table_unslice(P, world, last_blocks[0])
+            fins[(args.warmup - 1) & 1] = fin
+
+    materialise()
     if world > 1 and args.check:
         # every shard regenerated locally and reduced in one pass must equal the merged table, bit for bit
         allrecs = torch.cat([ctx.synth_fill(P, S, first_sample=k * S, seed=SEED, depth=depth) for k in range(world)])
@@ -402,6 +421,7 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
+    materialise()
     t_red = sum(ctx.elapsed_ms(ev[i][0], ev[i][1]) for i in ev_steps) / len(ev_steps)
     t_call_main = sum(ctx.elapsed_ms(ev[i][2], ev[i][3]) for i in ev_steps) / len(ev_steps)  # main-stream part (all of it unless --async-drain)
     ctx.wait_calls()

@@ -281,6 +281,12 @@ int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_
                        const uint8_t *d_ref_code, int32_t coverage_cutoff, int32_t mode,
                        uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
                        unsigned long long *d_n_calls, double *d_q, float *d_af);
+/* the same with the thresholds read straight from the all-gathered blocks of a position-sliced merge (d_blocks as
+ * ampli_error_table_unslice takes them): spares the unslice launch when only the calls are wanted */
+int ampli_poisson_call_blocks(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
+                              int32_t T, const void *d_blocks, int32_t n_slices, const uint8_t *d_ref_code,
+                              int32_t coverage_cutoff, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls,
+                              int64_t capacity, unsigned long long *d_n_calls, double *d_q, float *d_af);
 
 /* Asynchronous drain (opt-in).  In prefilter mode poisson_call is two kernels; the second (the dense drain of the
  * queued survivors) is one fp64 scorer chain long and independent of what the caller enqueues next.  With

@@ -201,7 +201,9 @@ def _sliced_merge_emulated(ctx, shards, P, firsts, E=0, dup_off=None, C_value=0.
     for k in range(n):
         recv = torch.stack([g.view(n, 8 * L)[k] for g in gms]).contiguous()  # all-to-all: chunk j = rank j's pair for slice k
         ctx.error_finalize_slice(P, n, k, total[k].contiguous(), recv, blocks[k * block_bytes:(k + 1) * block_bytes], C_value, cov)
-    return ctx.error_table_unslice(P, n, blocks)                         # all-gather: the blocks back to back
+    fin = ctx.error_table_unslice(P, n, blocks)                          # all-gather: the blocks back to back
+    fin.blocks = blocks
+    return fin
 
 
 @pytest.mark.parametrize("P,S,n", [(2000, 48, 2), (1000, 37, 3), (4097, 64, 8), (100, 16, 8), (15, 300, 2), (777, 130, 4)])
@@ -222,6 +224,28 @@ def test_sliced_merge_matches_single_pass(ctx, P, S, n):
     one = ctx.error_estimate(_t(recs), P)
     for a, b in ((fin.rate, one.rate), (fin.thr, one.thr), (fin.code, one.code), (fin.germ_present, one.germ_present)):
         assert bool((a == b).all()) or np.array_equal(a.cpu().numpy().view(np.uint8), b.cpu().numpy().view(np.uint8))
+
+
+@pytest.mark.parametrize("P,n", [(1000, 3), (4097, 8), (100, 8)])
+def test_poisson_call_reads_thresholds_from_the_gathered_blocks(ctx, P, n):
+    """ampli_poisson_call_blocks (thresholds straight from the blocks of a sliced merge) == ampli_poisson_call on the
+    unsliced table, both modes, and == the oracle."""
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+    from amplisolve_amd.dist import shard_range
+
+    S, T = 40, 5
+    recs = synth_recs(P, S)
+    cuts = [shard_range(S, r, n) for r in range(n)]
+    fin = _sliced_merge_emulated(ctx, [_t(recs[a:b]) for a, b in cuts], P, [a for a, _ in cuts])
+    ref_code = synth_ref(P)
+    trecs = synth_recs(P, T, tumour=True)
+    exp = orc.poisson_call(trecs, P, orc.error_finalize(orc.error_reduce(recs, P))["thr"], ref_code, 100)
+    for mode in (POISSON_PREFILTER, POISSON_FULL):
+        a = ctx.poisson_call(_t(trecs), P, fin.thr, _t(ref_code), 100, mode=mode, capacity=1 << 16)
+        b = ctx.poisson_call(_t(trecs), P, fin.blocks, _t(ref_code), 100, mode=mode, capacity=1 << 16, blocks_of=n)
+        assert np.array_equal(a["call_mask"].cpu().numpy(), exp["call_mask"])
+        assert np.array_equal(b["call_mask"].cpu().numpy(), exp["call_mask"])
+        assert ctx.read_calls(a).tobytes() == ctx.read_calls(b).tobytes()
 
 
 def test_sliced_merge_edge_cases_and_extras(ctx):
