@@ -128,6 +128,14 @@ def main(argv=None) -> int:
     dev = local % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     os.environ["AMPLISOLVE_DEVICE"] = str(dev)  # the C++ host opens its context on this device's default stream
+    if world == 1:  # started without a launcher: the one-process pipeline, no process group
+        lib = host_lib()
+        if entry.startswith("ampli_host_run_error"):
+            ref = os.environ.get("AMPLISOLVE_REFBASES_FILE")
+            rc = lib.ampli_host_run_error_estimation(*toks, ref.encode() if ref else None)
+        else:
+            rc = lib.ampli_host_run_variant_calling(*toks)
+        return 0 if rc == 0 else 1
     quiet = None
     if rank != 0 and not os.environ.get("AMPLISOLVE_ALL_RANKS_VERBOSE"):
         # the C++ pipeline narrates on stdout like the reference; one narrator is enough -- the others' text is kept

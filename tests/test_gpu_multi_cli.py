@@ -97,3 +97,16 @@ def test_failing_shard_ends_the_job(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
     assert r.returncode != 0
     assert "failed" in r.stderr and "Something went wrong" in (r.stdout + r.stderr)
+
+
+def test_without_a_launcher_it_is_the_one_process_pipeline(tmp_path):
+    d = f"{G}/toy_subset"
+    out = tmp_path / "solo"
+    e = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), AMPLISOLVE_REFBASES_FILE=f"{d}/refbases.txt")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "amplisolve_amd.multi", "AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed",
+                        "reference_genome=unused.fa", f"germline_dir={d}/NORMAL", "C_value=0.002", "coverage_cutoff=100", "default_error=0.01",
+                        f"output_dir={out}"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert (out / "positionSpecificNoise_0.0020.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0020.txt").read()
