@@ -1726,6 +1726,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         kfin.packed = nullptr; // packed after the merge, below
         kfin.slice_len = 0;
     }
+    if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE_L(FASTV, GV, UV)                                                                                      \
     hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, \
@@ -1981,6 +1982,7 @@ static int poisson_call_impl(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, 
     if (((uintptr_t)d_trecs & (ctx->rec_layout == AMPLI_RECORDS_U24 ? 7 : 15)) != 0)
         return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
     if (P + E >= (1ll << 30)) return fail(ctx, AMPLI_E_RANGE, "poisson_call: P + E must be below 2^30 records per sample");
+    if ((T + PC_SAMPLES - 1) / PC_SAMPLES > 65535) return fail(ctx, AMPLI_E_RANGE, "poisson_call: more than 262140 tumour samples in one call (grid limit); split the cohort");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rcj = join_drain(ctx); if (rcj) return rcj; } // the queue, its counters and the call list are about to be reused
     const long long R = P + E;
@@ -2012,6 +2014,7 @@ static int poisson_call_impl(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, 
         long long gy;
         if (const char *e = getenv("AMPLI_EXP_ROWS")) rows = std::max(1, atoi(e)); // experiment knob
         gy = (T + rows - 1) / rows;
+        while (gy > 65535) { rows *= 2; gy = (T + rows - 1) / rows; } // gridDim.y limit
         // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),
         // or what ampli_set_queue_items asked for plus one workgroup's worth of slack per shard (workgroups are dealt
         // to the shards round-robin, so a shard holds at most ceil(blocks/SHARDS) workgroups' items)
@@ -2114,7 +2117,7 @@ extern "C" int ampli_roundtrip_batch(ampli_ctx *ctx, const float *d_in, int64_t 
 extern "C" int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int32_t n_samples, int32_t first_sample,
                                 uint64_t seed, int32_t depth, int32_t tumour)
 {
-    if (!ctx || !d_recs || P <= 0 || n_samples <= 0 || depth <= 0) return AMPLI_E_INVALID;
+    if (!ctx || !d_recs || P <= 0 || n_samples <= 0 || n_samples > 65535 || depth <= 0) return AMPLI_E_INVALID; // n_samples = gridDim.y
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)n_samples), dim3(256), 0, ctx->stream,
                        (int4 *)d_recs, (long long)P, (int)n_samples, (int)first_sample, (unsigned long long)seed, (int)depth, (int)tumour);
