@@ -110,6 +110,9 @@ HOST_SYMBOLS = {
     "ampli_host_prefilter_skip_f32": (C.c_int, [i32, i32, f32]),
     "ampli_host_last_error": (C.c_char_p, []),
     "ampli_host_cohort_load": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "ampli_host_cohort_load_shard": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, i32, i32, C.POINTER(vp)]),
+    "ampli_host_cohort_first_sample": (i32, [vp]),
+    "ampli_host_cohort_total_samples": (i32, [vp]),
     "ampli_host_cohort_free": (None, [vp]),
     "ampli_host_cohort_P": (i64, [vp]),
     "ampli_host_cohort_E": (i64, [vp]),

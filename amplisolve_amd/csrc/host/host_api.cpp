@@ -16,8 +16,9 @@ static thread_local std::string g_err;
 
 extern "C" const char *ampli_host_last_error(void) { return g_err.c_str(); }
 
-extern "C" int ampli_host_cohort_load(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
-                                      const char *aseq_dir, int n_threads, int keep_line_no, ampli_host_cohort **out)
+static int cohort_load_impl(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
+                            const char *aseq_dir, int n_threads, int keep_line_no, int shard_index, int shard_count,
+                            ampli_host_cohort **out)
 {
     if (!bed_or_table || !out) return AMPLI_E_INVALID;
     *out = nullptr;
@@ -31,7 +32,7 @@ extern "C" int ampli_host_cohort_load(const char *bed_or_table, int is_error_tab
             if (refbases_file && *refbases_file) panel_load_refbases_file(h->panel, refbases_file);
             else if (fasta && *fasta) panel_load_fasta(h->panel, fasta);
         }
-        if (aseq_dir && *aseq_dir) cohort_load(h->panel, aseq_dir, "", n_threads, keep_line_no != 0, false, h->cohort);
+        if (aseq_dir && *aseq_dir) cohort_load(h->panel, aseq_dir, "", n_threads, keep_line_no != 0, false, h->cohort, shard_index, shard_count);
         else h->cohort.P = h->panel.P();
     } catch (const Error &e) {
         g_err = e.msg;
@@ -41,6 +42,22 @@ extern "C" int ampli_host_cohort_load(const char *bed_or_table, int is_error_tab
     *out = h;
     return 0;
 }
+
+extern "C" int ampli_host_cohort_load(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
+                                      const char *aseq_dir, int n_threads, int keep_line_no, ampli_host_cohort **out)
+{
+    return cohort_load_impl(bed_or_table, is_error_table, refbases_file, fasta, aseq_dir, n_threads, keep_line_no, 0, 1, out);
+}
+
+extern "C" int ampli_host_cohort_load_shard(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
+                                            const char *aseq_dir, int n_threads, int keep_line_no, int32_t shard_index,
+                                            int32_t shard_count, ampli_host_cohort **out)
+{
+    if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) { g_err = "bad shard"; return AMPLI_E_INVALID; }
+    return cohort_load_impl(bed_or_table, is_error_table, refbases_file, fasta, aseq_dir, n_threads, keep_line_no, shard_index, shard_count, out);
+}
+extern "C" int32_t ampli_host_cohort_first_sample(const ampli_host_cohort *h) { return h->cohort.first_sample; }
+extern "C" int32_t ampli_host_cohort_total_samples(const ampli_host_cohort *h) { return h->cohort.total_samples; }
 
 extern "C" void ampli_host_cohort_free(ampli_host_cohort *h) { delete h; }
 extern "C" int64_t ampli_host_cohort_P(const ampli_host_cohort *h) { return h->panel.P(); }

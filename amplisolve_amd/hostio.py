@@ -16,12 +16,15 @@ class HostCohort:
     """BED (or error table) + a directory of .PILEUP.ASEQ files, packed by the C++ host."""
 
     def __init__(self, bed_or_table, aseq_dir=None, refbases_file=None, fasta=None, is_error_table=False, threads=0,
-                 keep_line_no=False):
+                 keep_line_no=False, shard=None):
+        """shard = (index, count): parse only that contiguous range of the directory's visit order (dist.shard_range);
+        first_sample / total_samples then place it in the whole cohort."""
         lib = host_lib()
         h = C.c_void_p()
-        rc = lib.ampli_host_cohort_load(_b(bed_or_table), int(is_error_table), _b(refbases_file) if refbases_file else None,
-                                        _b(fasta) if fasta else None, _b(aseq_dir) if aseq_dir else None, threads,
-                                        int(keep_line_no), C.byref(h))
+        k, n = shard if shard is not None else (0, 1)
+        rc = lib.ampli_host_cohort_load_shard(_b(bed_or_table), int(is_error_table), _b(refbases_file) if refbases_file else None,
+                                              _b(fasta) if fasta else None, _b(aseq_dir) if aseq_dir else None, threads,
+                                              int(keep_line_no), k, n, C.byref(h))
         if rc != 0:
             raise AmpliError(f"ampli_host_cohort_load: {lib.ampli_host_last_error().decode()}")
         self._lib, self.h = lib, h
@@ -29,6 +32,8 @@ class HostCohort:
         self.E = lib.ampli_host_cohort_E(h)
         self.S = lib.ampli_host_cohort_S(h)
         self.walk_len = lib.ampli_host_cohort_walk_len(h)
+        self.first_sample = lib.ampli_host_cohort_first_sample(h)
+        self.total_samples = lib.ampli_host_cohort_total_samples(h)
         R = self.P + self.E
 
         def arr(ptr, shape, dtype):

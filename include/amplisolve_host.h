@@ -40,6 +40,13 @@ const char *ampli_host_last_error(void);
  * aseq_dir may be NULL (panel only).  Samples come out in the reference's visit order (EE:1081 / VC:672). */
 int ampli_host_cohort_load(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
                            const char *aseq_dir, int n_threads, int keep_line_no, ampli_host_cohort **out);
+/* the same for shard shard_index of shard_count: only that contiguous range of the visit order is parsed (one process per
+ * GPU; the ranges are those of amplisolve_amd/dist.py::shard_range).  first_sample = visit-order index of its sample 0 */
+int ampli_host_cohort_load_shard(const char *bed_or_table, int is_error_table, const char *refbases_file, const char *fasta,
+                                 const char *aseq_dir, int n_threads, int keep_line_no, int32_t shard_index, int32_t shard_count,
+                                 ampli_host_cohort **out);
+int32_t ampli_host_cohort_first_sample(const ampli_host_cohort *h);
+int32_t ampli_host_cohort_total_samples(const ampli_host_cohort *h);
 void ampli_host_cohort_free(ampli_host_cohort *h);
 int64_t ampli_host_cohort_P(const ampli_host_cohort *h);
 int64_t ampli_host_cohort_E(const ampli_host_cohort *h);

@@ -139,3 +139,33 @@ def test_multi_front_end_token_parsing_and_usage(capsys):
     assert multi._token("coverage=100", "coverage_cutoff") == "" and multi._token("p_value=", "p_value") == ""
     assert multi.main(["multi", "AmpliSolveVariantCalling", "errorFile=x"]) == 1  # wrong token count: usage, no GPU touched
     assert "usage" in capsys.readouterr().out
+
+
+def test_cohort_shards_partition_the_visit_order():
+    """ampli_host_cohort_load_shard: shard k of n holds exactly dist.shard_range(S, k, n) of the one-process cohort, record
+    for record (what every rank of amplisolve_amd.multi parses)."""
+    from amplisolve_amd.dist import shard_range
+
+    d = "/root/repo/tests/golden/mini_edge"
+    whole = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
+    S = whole.S
+    assert whole.first_sample == 0 and whole.total_samples == S and S >= 5
+    for n in (2, 3, S + 2):
+        seen = []
+        for k in range(n):
+            part = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt", shard=(k, n))
+            lo, hi = shard_range(S, k, n)
+            assert (part.first_sample, part.S, part.total_samples) == (lo, hi - lo, S)
+            assert part.names == whole.names[lo:hi]
+            if part.S:
+                # the extras layout is per shard (it depends on the files seen): compare the primary records and every extra
+                assert np.array_equal(part.recs[:, : whole.P], whole.recs[lo:hi, : whole.P])
+                for s in range(part.S):
+                    for p in range(whole.P):
+                        a = part.recs[s, part.P + part.dup_off[p]: part.P + part.dup_off[p + 1]]
+                        b = whole.recs[lo + s, whole.P + whole.dup_off[p]: whole.P + whole.dup_off[p + 1]]
+                        na = [r.tolist() for r in a if r[0] != np.iinfo(np.int32).min]
+                        nb = [r.tolist() for r in b if r[0] != np.iinfo(np.int32).min]
+                        assert na == nb
+            seen += part.names
+        assert seen == whole.names
