@@ -108,9 +108,14 @@ def main():
             flags = ctx.flags()
             if flags & 2:
                 raise AssertionError("fast kernel asked for a rerun on records inside its envelope")
+            if (int(fin1.flags.item()) | int(fin2.flags.item())) & 1:
+                # the double sums left the exactness envelope (tiny C x cutoff 1 with deep records): the product says so
+                # (flag bit 0; the command line refuses to write the table) and equality with the oracle is not promised
+                n["envelope_flagged"] = n.get("envelope_flagged", 0) + 1
+                continue
             for name in ("snt", "srd", "cnt", "nrec", "gm_n"):
                 if not eq_bits(getattr(acc, name).cpu().numpy(), o_acc[name]):
-                    raise AssertionError(f"accumulator plane {name}")
+                    raise AssertionError(f"accumulator plane {name} (and the envelope flag is clear)")
             check_final(fin2, o_fin, "two-step finalize")
             check_final(fin1, o_fin, "fused estimate")
             n["reduce"] += 1
