@@ -26,3 +26,14 @@ def test_bench_multirank_path_on_one_gpu(world, merge):
     d = json.loads(line)
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0 and "cpu_baseline" not in d
     assert d["config"]["merge"] == merge
+
+
+def test_rccl_calls_of_the_sliced_merge_on_a_size_one_communicator():
+    """The native path of dist.SlicedMerger (reduce_scatter_tensor f64, all_to_all_single f32, all_gather_into_tensor u8)
+    on a real RCCL communicator -- of size 1, all a one-GPU box offers -- in the bench's pipeline shape, with
+    poisson_call reading the gathered blocks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29591", os.path.join(ROOT, "tools", "nccl_selftest.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "nccl selftest ok" in r.stdout
