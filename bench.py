@@ -59,6 +59,8 @@ def parse_args():
                     help="N>1 exchange: sliced = reduce-scatter + all-to-all + all-gather by position slices (default); "
                          "allreduce = one packed all-reduce + all-gather of whole germ-max regions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, merge, pipelined loop) "
+                    "even with one rank -- over RCCL this exercises the real collectives on a one-GPU box")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
     return ap.parse_args()
 
@@ -167,6 +169,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    multi = world > 1 or args.force_dist  # the N>1 code path (also runs with one rank under --force-dist)
     import torch
     import torch.distributed as dist
 
@@ -177,7 +180,7 @@ def main():
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)  # == local_rank on a full node; ranks share a device only in rehearsals
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -204,7 +207,7 @@ def main():
         pn, ok_n = ctx.pack(normals, name)
         pt, ok_t = ctx.pack(tumours, name)
         fits = torch.tensor([1 if (ok_n and ok_t) else 0], dtype=torch.int32, device=ctx.device)
-        if world > 1:
+        if multi:
             dist.all_reduce(fits, op=dist.ReduceOp.MIN)  # one layout for the whole job
         if int(fits.item()):
             packed[name] = (pn, pt)
@@ -214,10 +217,10 @@ def main():
         raise SystemExit(f"--records {layout}: a count of this workload does not fit that layout")
     normals, tumours = packed[layout]
     ctx.set_record_layout(layout)
-    if world > 1 or args.streams > 1:
+    if multi or args.streams > 1:
         packed = {layout: packed[layout]}  # the other layouts are only kept for the N = 1 comparison legs
     rec_bytes = REC_BYTES[layout]
-    accs = [ctx.new_acc(P) for _ in range(2 if world > 1 else 1)]
+    accs = [ctx.new_acc(P) for _ in range(2 if multi else 1)]
     for a in accs:
         a.buf.zero_()
     acc = accs[0]
@@ -233,9 +236,9 @@ def main():
     n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=ctx.device)
     from amplisolve_amd.dist import SlicedMerger
 
-    sliced = world > 1 and args.merge == "sliced"
+    sliced = multi and args.merge == "sliced"
     merger = None
-    if world > 1:
+    if multi:
         merger = (SlicedMerger(P, world, rank, ctx.device) if sliced else
                   TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack))
 
@@ -255,7 +258,7 @@ def main():
         timed = timed and i % max(1, args.event_every) == 0
         if timed:
             ctx.record(ev[i][0])
-        if world == 1:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
+        if not multi:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
             fins[i & 1] = fin = ctx.error_estimate(normals, P, 0.002, 100, out=fins[i & 1])
         elif sliced:  # shard of a multi-GPU panel: sums and germ-max pairs straight into the slice-major exchange buffers
             ctx.error_reduce_sliced(normals, P, world, merger.sums[slot], merger.gm[slot], 0.002, 100, first_sample=rank * S)
@@ -278,7 +281,7 @@ def main():
                 ctx.record(ev[i][3])
             last_blocks[0] = merger.blocks[slot]
             return
-        elif world > 1:  # finalize straight from the all-reduced sums + gathered germ-max regions
+        elif multi:  # finalize straight from the all-reduced sums + gathered germ-max regions
             fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
         if timed:
             ctx.record(ev[i][2])
@@ -293,7 +296,7 @@ def main():
         error_reduce of batch i+1; every batch still goes through every stage inside the timed region."""
         if n <= 0:
             return
-        if world == 1:
+        if not multi:
             for i in range(n):
                 reduce_part(i, timed, 0)
                 call_part(i, timed, 0)
@@ -341,12 +344,12 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
     lanes = None
-    if world == 1 and args.streams > 1:
+    if not multi and args.streams > 1:
         # extra lanes: own stream + own outputs each; inputs are shared (read-only)
         lanes = []
         for _ in range(args.streams):
@@ -396,7 +399,7 @@ def main():
             fins[(args.warmup - 1) & 1] = fin
 
     materialise()
-    if world > 1 and args.check:
+    if multi and args.check:
         # every shard regenerated locally and reduced in one pass must equal the merged table, bit for bit
         allrecs = torch.cat([ctx.synth_fill(P, S, first_sample=k * S, seed=SEED, depth=depth) for k in range(world)])
         allrecs, _ = ctx.pack(allrecs, layout)
@@ -416,7 +419,7 @@ def main():
     run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         te = torch.tensor([elapsed], dtype=torch.float64, device=ctx.device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -451,7 +454,7 @@ def main():
         raise SystemExit("error_finalize reported an exactness-envelope violation")
 
     others = []
-    for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and world == 1 and lanes is None]:
+    for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and not multi and lanes is None]:
         # the same workload in the other record layouts, outside the timed region, for comparison
         an, at = packed[name]
         c2 = Context(dev_index)
@@ -492,7 +495,7 @@ def main():
         # algorithmic bytes of error_reduce per launch: the records + what it writes (the accumulator table,
         # or at N = 1 the finalised error table: rate 32 B + thr 32 B + code 4 B + germ 16+4 B per position)
         # (N > 1, sliced merge: 21 doubles + 8 floats per position into the exchange buffers = 200 B)
-        red_bytes = rec_bytes * P * S + ((200 * P if sliced else acc_bytes) if world > 1 else 88 * P)
+        red_bytes = rec_bytes * P * S + ((200 * P if sliced else acc_bytes) if multi else 88 * P)
         call_bytes = rec_bytes * P * T + 33 * P + P * T    # poisson_call: records + thresholds/ref + mask
         lay = {"i32": 0, "u16": 1, "u24": 2}[layout]
         if t_red >= t_call:
@@ -505,7 +508,7 @@ def main():
         # under profiles/.  null when the workload is not the profiled one.
         traffic = None
         pj = os.path.join(ROOT, "profiles", "r01", "pmc_summary.json")
-        if args.config == "c3" and world == 1 and os.path.exists(pj):
+        if args.config == "c3" and not multi and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
                 traffic = sum(pm[k].get("hbm_bytes_per_launch", 0.0) for k in pm
@@ -526,9 +529,10 @@ def main():
             "dtype": {"i32": "int32", "u24": "24-bit", "u16": "uint16"}[layout] + " counts; f64 sums / Poisson; f32 rates",
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "depth": depth,
-                       "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if world == 1 else 1,
-                       "parallelism": f"tumour+normal sample shards x{world}" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table; three batches in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if world > 1 else ""),
-                       "merge": (args.merge if world > 1 else None),
+                       "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if not multi else 1,
+                       "parallelism": f"tumour+normal sample shards x{world}" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table; three batches in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if multi else ""),
+                       "merge": (args.merge if multi else None),
+                       "rehearsal": ("N>1 code path forced on one rank (--force-dist)" if args.force_dist and world == 1 else None),
                        "records": f"{layout} ({rec_bytes} B per record: 8 fields x {rec_bytes // 8 * 8} bits)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
@@ -542,14 +546,14 @@ def main():
         }
         if others:
             out["other_record_layouts"] = others
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg)
             except Exception as e:  # the baseline leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "position-evaluations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
