@@ -61,6 +61,7 @@ HIP_SYMBOLS = {
     "ampli_set_record_layout": (C.c_int, [vp, i32]),
     "ampli_records_pack16": (C.c_int, [vp, vp, i64, vp, vp]),
     "ampli_records_pack24": (C.c_int, [vp, vp, i64, vp, vp]),
+    "ampli_set_slice_group": (C.c_int, [vp, i32, i32]),
     "ampli_slice_len": (i64, [i64, i32]),
     "ampli_slice_bytes": (C.c_int, [i64, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "ampli_error_reduce_sliced": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, i32, vp, vp]),

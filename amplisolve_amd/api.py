@@ -268,6 +268,11 @@ class Context:
         return out
 
     # ---- position-sliced merge (reduce-scatter / all-to-all / all-gather; include/amplisolve_hip.h) ----
+    def set_slice_group(self, group_size: int = 1, group_index: int = 0):
+        """The sliced exchange buffers hold group_size batches per slice chunk; the following sliced calls address batch
+        group_index (include/amplisolve_hip.h, ampli_set_slice_group)."""
+        self._check(self.lib.ampli_set_slice_group(self.h, group_size, group_index))
+
     def slice_len(self, P: int, n_slices: int) -> int:
         return int(self.lib.ampli_slice_len(P, n_slices))
 

@@ -36,6 +36,7 @@ struct ampli_ctx {
     int reduce_splits = 0; // 0 = auto
     int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
+    int grp_size = 1, grp_index = 0; // sliced exchange buffers hold grp_size batches per slice chunk; calls address batch grp_index
     int rec_layout = 0;     // record layout of every d_recs / d_trecs argument: AMPLI_RECORDS_I32 / _U16 / _U24
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
     void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
@@ -288,6 +289,15 @@ extern "C" int ampli_set_record_layout(ampli_ctx *ctx, int32_t layout)
     if (layout != AMPLI_RECORDS_I32 && layout != AMPLI_RECORDS_U16 && layout != AMPLI_RECORDS_U24)
         return fail(ctx, AMPLI_E_INVALID, "set_record_layout: unknown layout");
     ctx->rec_layout = layout;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_set_slice_group(ampli_ctx *ctx, int32_t group_size, int32_t group_index)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (group_size < 1 || group_index < 0 || group_index >= group_size) return fail(ctx, AMPLI_E_INVALID, "set_slice_group: 0 <= index < size");
+    ctx->grp_size = group_size;
+    ctx->grp_index = group_index;
     return AMPLI_OK;
 }
 
@@ -588,6 +598,8 @@ struct FinOut {
     long long slice_len; // 0: `packed` is plane-major over the whole panel (above)
     double *sl_sums;     // [n_slices][21][slice_len]: the same 21 additive planes, slice-major
     float *sl_gm;        // [n_slices][8][slice_len]: germ-max first_af[4] (-1 = no qualifying record) | rest[4]
+    long long sl_group;  // batches per slice chunk (ampli_set_slice_group): chunk k of this batch starts k*sl_group*{21,8}*slice_len
+                         //  elements behind sl_sums / sl_gm (which already point at this batch's part of chunk 0)
 };
 
 __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, const long long P, const long long p, const LaneAcc &a)
@@ -607,8 +619,8 @@ __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, c
 __device__ __forceinline__ void lane_acc_store_sliced(const FinOut &o, const long long p, const LaneAcc &a)
 {
     const long long L = o.slice_len, k = p / L, q = p - k * L;
-    double *__restrict__ pk = o.sl_sums + (size_t)k * 21 * L + q;
-    float *__restrict__ gm = o.sl_gm + (size_t)k * 8 * L + q;
+    double *__restrict__ pk = o.sl_sums + (size_t)k * o.sl_group * 21 * L + q;
+    float *__restrict__ gm = o.sl_gm + (size_t)k * o.sl_group * 8 * L + q;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         pk[(0 * 4 + nt) * L] = a.snt[0][nt];
@@ -1164,6 +1176,7 @@ __device__ __forceinline__ FinOut slice_block_view(char *blk, const long long L)
 }
 
 __global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double *__restrict__ sums, const float *__restrict__ gm,
+                                                                   const size_t gm_stride /* elements between the shards' pairs */,
                                                                    const int nparts, const long long L, const long long p0,
                                                                    const long long P, const float C, const int cov, char *blk)
 {
@@ -1176,9 +1189,9 @@ __global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double 
     int n = 0;
     float rest = -INFINITY;
     for (int k = 0; k < nparts; ++k) { // L (+) R = (L.first, max(L.rest, R.first_af, R.rest)), shards in sample order
-        const float fa = gm[((size_t)k * 8 + nt) * L + q];
+        const float fa = gm[(size_t)k * gm_stride + (size_t)nt * L + q];
         if (fa < 0.0f) continue; // shard without a qualifying record
-        const float rr = gm[((size_t)k * 8 + 4 + nt) * L + q];
+        const float rr = gm[(size_t)k * gm_stride + (size_t)(4 + nt) * L + q];
         if (n == 0) { rest = rr; n = (rr > -INFINITY) ? 2 : 1; } // n: 0, 1 or "more than one"
         else { if (rest <= fa) rest = fa; if (rest <= rr) rest = rr; n = 2; }
     }
@@ -1189,18 +1202,18 @@ __global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double 
     if (bad) atomicOr(o.flags, 1);
 }
 
-__global__ __launch_bounds__(256) void error_table_unslice_kernel(const char *__restrict__ blocks, const int nparts, const long long L,
-                                                                  const long long P, const FinOut o)
+__global__ __launch_bounds__(256) void error_table_unslice_kernel(const char *__restrict__ blocks, const size_t block_stride,
+                                                                  const int nparts, const long long L, const long long P, const FinOut o)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p == 0 && o.flags) {
         int f = 0;
-        for (int k = 0; k < nparts; ++k) f |= *(const int *)(blocks + (size_t)k * slice_block_bytes(L) + (size_t)L * 88);
+        for (int k = 0; k < nparts; ++k) f |= *(const int *)(blocks + (size_t)k * block_stride + (size_t)L * 88);
         if (f) atomicOr(o.flags, f);
     }
     if (p >= P) return;
     const long long k = p / L, q = p - k * L;
-    const FinOut b = slice_block_view(const_cast<char *>(blocks) + (size_t)k * slice_block_bytes(L), L);
+    const FinOut b = slice_block_view(const_cast<char *>(blocks) + (size_t)k * block_stride, L);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         o.rate[j * P + p] = b.rate[j * L + q];
@@ -1855,8 +1868,9 @@ extern "C" int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, 
     if (!d_sums || !d_gm || n_slices < 1) return fail(ctx, AMPLI_E_INVALID, "error_reduce_sliced: exchange buffers and n_slices >= 1 are required");
     FinOut fo = {};
     fo.slice_len = ampli_slice_len(P, n_slices);
-    fo.sl_sums = d_sums;
-    fo.sl_gm = d_gm;
+    fo.sl_group = ctx->grp_size; // buffers [n_slices][group][planes][L]; this call fills batch grp_index
+    fo.sl_sums = d_sums + (size_t)ctx->grp_index * 21 * (size_t)fo.slice_len;
+    fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
     return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, nullptr, fo);
 }
 
@@ -1868,8 +1882,10 @@ extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_s
         return fail(ctx, AMPLI_E_INVALID, "error_finalize_slice: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long L = ampli_slice_len(P, n_slices);
-    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((4 * L + 255) / 256)), dim3(256), 0, ctx->stream, d_sum_slice,
-                       d_gm_recv, (int)n_slices, L, (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block);
+    const size_t G = (size_t)ctx->grp_size, g = (size_t)ctx->grp_index; // [group][21][L] sums, [n][group][8][L] pairs, [group][block] out
+    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((4 * L + 255) / 256)), dim3(256), 0, ctx->stream,
+                       d_sum_slice + g * 21 * (size_t)L, d_gm_recv + g * 8 * (size_t)L, G * 8 * (size_t)L, (int)n_slices, L,
+                       (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block + g * slice_block_bytes(L));
     return check_launch(ctx, "error_finalize_slice_kernel");
 }
 
@@ -1881,8 +1897,10 @@ extern "C" int ampli_error_table_unslice(ampli_ctx *ctx, int64_t P, int32_t n_sl
     if (P <= 0 || n_slices < 1 || !d_blocks || !d_rate || !d_code) return fail(ctx, AMPLI_E_INVALID, "error_table_unslice: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
+    const long long L = ampli_slice_len(P, n_slices);
     hipLaunchKernelGGL(error_table_unslice_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const char *)d_blocks, (int)n_slices, (long long)ampli_slice_len(P, n_slices), (long long)P, fo);
+                       (const char *)d_blocks + (size_t)ctx->grp_index * slice_block_bytes(L), (size_t)ctx->grp_size * slice_block_bytes(L),
+                       (int)n_slices, L, (long long)P, fo);
     return check_launch(ctx, "error_table_unslice_kernel");
 }
 
@@ -2092,7 +2110,8 @@ extern "C" int ampli_poisson_call_blocks(ampli_ctx *ctx, const int32_t *d_trecs,
     if (!ctx) return AMPLI_E_INVALID;
     if (n_slices < 1 || P <= 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call_blocks: bad argument");
     const long long L = ampli_slice_len(P, n_slices);
-    return poisson_call_impl(ctx, d_trecs, P, E, d_ext_pos, T, (const float *)d_blocks, L, slice_block_bytes(L), d_ref_code, cov, mode,
+    d_blocks = (const char *)d_blocks + (size_t)ctx->grp_index * slice_block_bytes(L); // [n_slices][group][block]: this batch's blocks
+    return poisson_call_impl(ctx, d_trecs, P, E, d_ext_pos, T, (const float *)d_blocks, L, (size_t)ctx->grp_size * slice_block_bytes(L), d_ref_code, cov, mode,
                              d_call_mask, d_calls, capacity, d_n_calls, d_q, d_af);
 }
 

@@ -149,13 +149,17 @@ class SlicedMerger:
     tensors (gloo: rehearsals and CPU tests) get the same data movement out of all-reduce / all-gather.
     """
 
-    def __init__(self, P: int, world: int, rank: int, device, group=None, depth: int = 3):
+    def __init__(self, P: int, world: int, rank: int, device, group=None, depth: int = 3, batches: int = 1):
+        """batches = G > 1: every buffer holds G independent batches per slice chunk (ampli_set_slice_group(ctx, G, g)
+        selects the batch a kernel call addresses) and ONE round of collectives serves all of them -- fewer, larger
+        messages and a third of the cross-stream waits per batch."""
         import torch
         import torch.distributed as dist
 
-        self.P, self.world, self.rank, self.group, self.depth = P, world, rank, group, depth
+        self.P, self.world, self.rank, self.group, self.depth, self.batches = P, world, rank, group, depth, batches
         self.L, sums_bytes, gm_bytes, self.block_bytes = slice_geometry(P, world)
-        L = self.L
+        L = self.L * batches  # every plane length below is per slice chunk = `batches` batches back to back
+        sums_bytes, gm_bytes = sums_bytes * batches, gm_bytes * batches
         self.native = dist.get_backend(group) == "nccl"
         z = dict(device=device)
         # zeroed once: entries of the padding positions (>= P) are never written by the kernels
@@ -163,15 +167,15 @@ class SlicedMerger:
         self.gm = [torch.zeros(world * 8 * L, dtype=torch.float32, **z) for _ in range(depth)]
         self.sum_slice = [torch.zeros(21 * L, dtype=torch.float64, **z) for _ in range(depth)]
         self.gm_recv = [torch.zeros(world * 8 * L, dtype=torch.float32, **z) for _ in range(depth)]
-        self.block = [torch.zeros(self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
-        self.blocks = [torch.zeros(world * self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
+        self.block = [torch.zeros(batches * self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
+        self.blocks = [torch.zeros(world * batches * self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
         self._a2a_tmp = None if self.native else torch.zeros(world * world * 8 * L, dtype=torch.float32, **z)
         assert sums_bytes == self.sums[0].numel() * 8 and gm_bytes == self.gm[0].numel() * 4
 
     def start_exchange(self, slot: int):
         import torch.distributed as dist
 
-        L, w, r = self.L, self.world, self.rank
+        L, w, r = self.L * self.batches, self.world, self.rank
         if self.native:
             h1 = dist.reduce_scatter_tensor(self.sum_slice[slot], self.sums[slot], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             h2 = dist.all_to_all_single(self.gm_recv[slot], self.gm[slot], group=self.group, async_op=True)

@@ -59,6 +59,8 @@ def parse_args():
                     help="N>1 exchange: sliced = reduce-scatter + all-to-all + all-gather by position slices (default); "
                          "allreduce = one packed all-reduce + all-gather of whole germ-max regions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--group", type=int, default=4, help="N>1, sliced merge: independent batches per round of collectives "
+                    "(fewer, larger RCCL messages and fewer cross-stream waits per batch)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, merge, pipelined loop) "
                     "even with one rank -- over RCCL this exercises the real collectives on a one-GPU box")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
@@ -239,7 +241,7 @@ def main():
     sliced = multi and args.merge == "sliced"
     merger = None
     if multi:
-        merger = (SlicedMerger(P, world, rank, ctx.device) if sliced else
+        merger = (SlicedMerger(P, world, rank, ctx.device, batches=max(1, args.group)) if sliced else
                   TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack))
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
@@ -252,6 +254,7 @@ def main():
         ctx.set_async_drain(True)
 
     last_blocks = [None]
+    G = max(1, args.group)  # batches per round of collectives (sliced merge)
 
     def reduce_part(i, timed, slot):
         nonlocal fin
@@ -279,7 +282,7 @@ def main():
                              calls_buf=calls_buf, n_calls=n_calls, blocks_of=world)
             if timed:
                 ctx.record(ev[i][3])
-            last_blocks[0] = merger.blocks[slot]
+            last_blocks[0] = (merger.blocks[slot], i % G)
             return
         elif multi:  # finalize straight from the all-reduced sums + gathered germ-max regions
             fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
@@ -302,31 +305,42 @@ def main():
                 call_part(i, timed, 0)
             return
         if sliced:
-            # three batches in flight: reduce(i) -> [reduce-scatter + all-to-all](i) | finalize_slice(i-1) -> [all-gather](i-1)
-            # | unslice + poisson_call(i-2); each collective has a whole error_reduce between its start and its wait
+            # three GROUPS of G batches in flight: G x reduce -> [reduce-scatter + all-to-all](group) | G x finalize_slice ->
+            # [all-gather](group - 1) | G x poisson_call(group - 2); one round of collectives serves the G batches of a group,
+            # and each collective has G whole error_reduce launches between its start and its wait
             hx, hg = {}, {}
+            ngroups = (n + G - 1) // G
 
-            def mid(j):
-                sj = j % 3
-                merger.wait(hx.pop(j))
-                ctx.error_finalize_slice(P, world, rank, merger.sum_slice[sj], merger.gm_recv[sj], merger.block[sj], 0.002, 100)
-                hg[j] = merger.start_gather(sj)
+            def members(gi):
+                return range(gi * G, min(n, (gi + 1) * G))
 
-            def last(j):
-                merger.wait(hg.pop(j))
-                call_part(j, timed, j % 3)
+            def mid(gi):
+                sj = gi % 3
+                merger.wait(hx.pop(gi))
+                for i in members(gi):
+                    ctx.set_slice_group(G, i % G)
+                    ctx.error_finalize_slice(P, world, rank, merger.sum_slice[sj], merger.gm_recv[sj], merger.block[sj], 0.002, 100)
+                hg[gi] = merger.start_gather(sj)
 
-            for i in range(n):
-                reduce_part(i, timed, i % 3)
-                hx[i] = merger.start_exchange(i % 3)
-                if i >= 1:
-                    mid(i - 1)
-                if i >= 2:
-                    last(i - 2)
-            mid(n - 1)
-            if n >= 2:
-                last(n - 2)
-            last(n - 1)
+            def last(gi):
+                merger.wait(hg.pop(gi))
+                for i in members(gi):
+                    ctx.set_slice_group(G, i % G)
+                    call_part(i, timed, gi % 3)
+
+            for gi in range(ngroups):
+                for i in members(gi):
+                    ctx.set_slice_group(G, i % G)
+                    reduce_part(i, timed, gi % 3)
+                hx[gi] = merger.start_exchange(gi % 3)
+                if gi >= 1:
+                    mid(gi - 1)
+                if gi >= 2:
+                    last(gi - 2)
+            mid(ngroups - 1)
+            if ngroups >= 2:
+                last(ngroups - 2)
+            last(ngroups - 1)
             return
         pending = None
         for i in range(n):
@@ -395,7 +409,10 @@ def main():
         """sliced merge: the plane-major table of the last finished batch (outside the per-batch work)"""
         nonlocal fin
         if sliced and last_blocks[0] is not None:
-            fin = ctx.error_table_unslice(P, world, last_blocks[0])
+            blocks, g = last_blocks[0]
+            ctx.set_slice_group(G, g)
+            fin = ctx.error_table_unslice(P, world, blocks)
+            ctx.set_slice_group(1, 0)
             fins[(args.warmup - 1) & 1] = fin
 
     materialise()
@@ -530,8 +547,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "depth": depth,
                        "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if not multi else 1,
-                       "parallelism": f"tumour+normal sample shards x{world}" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table; three batches in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if multi else ""),
-                       "merge": (args.merge if multi else None),
+                       "parallelism": f"tumour+normal sample shards x{world}" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table -- one round of collectives per group of independent batches, three groups in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if multi else ""),
+                       "merge": (args.merge if multi else None), "batches_per_exchange": (G if sliced else None),
                        "rehearsal": ("N>1 code path forced on one rank (--force-dist)" if args.force_dist and world == 1 else None),
                        "records": f"{layout} ({rec_bytes} B per record: 8 fields x {rec_bytes // 8 * 8} bits)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

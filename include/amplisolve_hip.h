@@ -210,6 +210,12 @@ int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const double *d_packe
  *   ampli_error_table_unslice   blocks -> the plane-major error table ([2][4][P] ...) every other entry point uses;
  *                               ORs the blocks' flags into *d_flags
  * Results are bit-identical to ampli_error_estimate over all shards in order. */
+/* Several independent batches can share ONE round of collectives (fewer, larger messages; fewer cross-stream waits):
+ * with ampli_set_slice_group(ctx, G, g) the exchange buffers hold G batches per slice chunk -- d_sums
+ * [n][G][21][L], d_gm [n][G][8][L], the reduce-scattered / all-to-all'ed / gathered buffers accordingly [G][21][L],
+ * [n][G][8][L], [G][block], [n][G][block] -- and every call of the four entry points below (and of
+ * ampli_poisson_call_blocks) addresses batch g of the group.  Default G = 1, g = 0. */
+int ampli_set_slice_group(ampli_ctx *ctx, int32_t group_size, int32_t group_index);
 int64_t ampli_slice_len(int64_t P, int32_t n_slices);
 int ampli_slice_bytes(int64_t P, int32_t n_slices, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes);
 int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,

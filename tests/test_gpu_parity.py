@@ -248,6 +248,46 @@ def test_poisson_call_reads_thresholds_from_the_gathered_blocks(ctx, P, n):
         assert ctx.read_calls(a).tobytes() == ctx.read_calls(b).tobytes()
 
 
+def test_sliced_merge_with_groups_of_batches(ctx):
+    """ampli_set_slice_group: G independent batches share one round of collectives (buffers [n][G][planes][L]); every
+    batch of the group comes out as its own single pass, and poisson_call reads the right batch's blocks."""
+    import torch
+
+    from amplisolve_amd.api import POISSON_PREFILTER
+    from amplisolve_amd.dist import shard_range, slice_geometry
+
+    P, S, n, G, T = 1000, 24, 3, 2, 4
+    L, _, _, bb = slice_geometry(P, n)
+    batches = [synth_recs(P, S, seed=900 + g) for g in range(G)]
+    cuts = [shard_range(S, r, n) for r in range(n)]
+    sums = [torch.zeros(n * G * 21 * L, dtype=torch.float64, device="cuda") for _ in range(n)]
+    gms = [torch.zeros(n * G * 8 * L, dtype=torch.float32, device="cuda") for _ in range(n)]
+    try:
+        for r, (a, b) in enumerate(cuts):
+            for g in range(G):
+                ctx.set_slice_group(G, g)
+                ctx.error_reduce_sliced(_t(batches[g][a:b]), P, n, sums[r], gms[r], first_sample=a)
+        total = torch.stack(sums).sum(0).view(n, G * 21 * L)                       # reduce-scatter: rank k keeps chunk k
+        block = [torch.zeros(G * bb, dtype=torch.uint8, device="cuda") for _ in range(n)]
+        for k in range(n):
+            recv = torch.stack([gm.view(n, G * 8 * L)[k] for gm in gms]).contiguous()  # all-to-all
+            for g in range(G):
+                ctx.set_slice_group(G, g)
+                ctx.error_finalize_slice(P, n, k, total[k].contiguous(), recv, block[k])
+        blocks = torch.cat(block)                                                   # all-gather: [n][G][block]
+        ref_code = synth_ref(P)
+        trecs = synth_recs(P, T, tumour=True)
+        for g in range(G):
+            ctx.set_slice_group(G, g)
+            fin = ctx.error_table_unslice(P, n, blocks)
+            assert_final_equal(fin, orc.error_finalize(orc.error_reduce(batches[g], P)))
+            a = ctx.poisson_call(_t(trecs), P, blocks, _t(ref_code), 100, mode=POISSON_PREFILTER, capacity=1 << 16, blocks_of=n)
+            b = ctx.poisson_call(_t(trecs), P, fin.thr, _t(ref_code), 100, mode=POISSON_PREFILTER, capacity=1 << 16)
+            assert torch.equal(a["call_mask"], b["call_mask"])
+    finally:
+        ctx.set_slice_group(1, 0)
+
+
 def test_sliced_merge_edge_cases_and_extras(ctx):
     """Edge-case records (absent cells, depth around the cutoff, AF around 5 %, quorum failures, NaN rates) with
     positions listed more than once per file, sharded down to one sample per rank so that many shards have no
