@@ -1,14 +1,17 @@
 // amplisolve_amd/csrc/ampli_kernels.hip -- HIP kernels + C ABI of libamplisolve_hip.so (gfx950, wave64).
 //
-// Kernels (HBM-bound integer / scalar-FP work, no MFMA):
-//   error_reduce_kernel<FAST,G>   EE:1149-1296 (+clones), EE:1565-1631 (+clones)      32 B read per (position, sample);
-//                                 optional fused epilogue = finalize_lane, or packed sums for the multi-GPU merge
+// Kernels (HBM-bound integer / scalar-FP work, no MFMA); LAY = record layout (32 / 24 / 16 bytes per record):
+//   error_reduce_kernel<FAST,G,LAY>   EE:1149-1296 (+clones), EE:1565-1631 (+clones)   one record read per (position, sample);
+//                                 epilogue: fused finalize_lane (one GPU), packed sums (all-reduce merge) or slice-major
+//                                 sums + germ-max pairs (position-sliced merge)
 //   acc_merge_kernel / acc_merge_ptr_kernel / gm_merge_kernel   ordered combines of partial accumulator tables
-//   acc_pack_kernel / acc_unpack_kernel                         additive planes <-> one float64 all-reduce buffer
-//   error_finalize_kernel / error_finalize_merged_kernel        EE:1659-1714 (+clones), sentinel rule EE:1260/1318/1374/1431,
-//                                                               text round trip EE:1704 -> VC:889
-//   poisson_stream_kernel + poisson_drain_kernel   VC:752-898 (+clones), VC:3721-3884   32 B read per (position, tumour)
-//   poisson_call_kernel<MODE>                      the same evaluated in place (validation mode, dense outputs)
+//   acc_pack_kernel / acc_unpack_kernel / acc_pack_sliced_kernel   additive planes <-> exchange buffers
+//   error_finalize_kernel / error_finalize_merged_kernel / error_finalize_slice_kernel
+//                                 EE:1659-1714 (+clones), sentinel rule EE:1260/1318/1374/1431, text round trip EE:1704 -> VC:889
+//   error_table_unslice_kernel    gathered blocks of a sliced merge -> plane-major error table
+//   poisson_stream_kernel<LAY> + poisson_drain_kernel   VC:752-898 (+clones), VC:3721-3884   one record read per (position, tumour)
+//   poisson_call_kernel<MODE,LAY>                  the same evaluated in place (validation mode, dense outputs)
+//   records_pack16_kernel / records_pack24_kernel  int32 records -> the packed layouts
 // See include/amplisolve_hip.h for the data layout and DESIGN.md for the rooflines.
 #include <hip/hip_runtime.h>
 
