@@ -558,7 +558,10 @@ def main():
                         "poisson_call_ms": t_call, "poisson_call_GBs": call_bytes / (t_call * 1e-3) / 1e9,
                         "poisson_call_main_stream_ms": t_call_main, "drain": "side stream, overlapped with the next batch" if args.async_drain else "main stream",
                         "poisson_call_full_mode_ms": t_call_full,
-                        "R_EE_positions_per_s": P / (t_red * 1e-3), "R_VC_evals_per_s": P * T / (t_call * 1e-3)},
+                        # SURVEY.md 8d's three rates: panel positions/s through error estimation, tumour position-evaluations/s
+                        # through calling, and tumour position-evaluations/s through the whole pass
+                        "R_EE_positions_per_s": P / (t_red * 1e-3), "R_VC_evals_per_s": P * T / (t_call * 1e-3),
+                        "R_pipe_evals_per_s": world * P * T / (ms_per_step * 1e-3)},
             "calls_per_step": n_found,
         }
         if others:
