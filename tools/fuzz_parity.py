@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=None, help="replay one case by its printed seed")
+    ap.add_argument("--big", action="store_true", help="larger panels and cohorts (fewer cases per second)")
     args = ap.parse_args()
     ctxs = {"i32": Context(0), "u16": Context(0), "u24": Context(0)}
     for k, c in ctxs.items():
@@ -70,10 +71,16 @@ def main():
             break
         rng = np.random.default_rng(seed)
         try:
-            P = int(rng.choice([1, 7, 63, 64, 65, 255, 256, 257, 1000, 4097, int(rng.integers(1, 6000))]))
-            S = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 33, 64, 130, 300]))
-            if P * S > 600_000:
-                S = max(1, 600_000 // P)
+            if args.big:
+                P = int(rng.choice([4097, 20_000, 65_536, int(rng.integers(1000, 60_000))]))
+                S = int(rng.choice([5, 33, 64, 130, 300, 700, 1100]))
+                cap_cells = 6_000_000
+            else:
+                P = int(rng.choice([1, 7, 63, 64, 65, 255, 256, 257, 1000, 4097, int(rng.integers(1, 6000))]))
+                S = int(rng.choice([1, 2, 3, 4, 5, 8, 17, 33, 64, 130, 300]))
+                cap_cells = 600_000
+            if P * S > cap_cells:
+                S = max(1, cap_cells // P)
             dups = rng.random() < 0.4
             mult = np.zeros(P, np.int64)
             if dups:
