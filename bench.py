@@ -59,8 +59,9 @@ def parse_args():
                     help="N>1 exchange: sliced = reduce-scatter + all-to-all + all-gather by position slices (default); "
                          "allreduce = one packed all-reduce + all-gather of whole germ-max regions")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
-    ap.add_argument("--group", type=int, default=4, help="N>1, sliced merge: independent batches per round of collectives "
-                    "(fewer, larger RCCL messages and fewer cross-stream waits per batch)")
+    ap.add_argument("--group", type=int, default=0, help="N>1, sliced merge: independent batches per round of collectives "
+                    "(fewer, larger RCCL messages and fewer cross-stream waits per batch); 0 = auto: 4 for runs of >= 16 steps, "
+                    "2 for >= 8, else 1 (the last group's exchange has nothing to hide behind, so short runs want small groups)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, merge, pipelined loop) "
                     "even with one rank -- over RCCL this exercises the real collectives on a one-GPU box")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
@@ -239,9 +240,10 @@ def main():
     from amplisolve_amd.dist import SlicedMerger
 
     sliced = multi and args.merge == "sliced"
+    G = args.group if args.group > 0 else (4 if args.steps >= 16 else 2 if args.steps >= 8 else 1)  # batches per round of collectives
     merger = None
     if multi:
-        merger = (SlicedMerger(P, world, rank, ctx.device, batches=max(1, args.group)) if sliced else
+        merger = (SlicedMerger(P, world, rank, ctx.device, batches=G) if sliced else
                   TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack))
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
@@ -254,7 +256,6 @@ def main():
         ctx.set_async_drain(True)
 
     last_blocks = [None]
-    G = max(1, args.group)  # batches per round of collectives (sliced merge)
 
     def reduce_part(i, timed, slot):
         nonlocal fin

@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,merge", [(2, "sliced"), (3, "sliced"), (2, "allreduce")])
-def test_bench_multirank_path_on_one_gpu(world, merge):
+@pytest.mark.parametrize("world,merge,group", [(2, "sliced", 1), (3, "sliced", 2), (2, "sliced", 4), (2, "allreduce", 1)])
+def test_bench_multirank_path_on_one_gpu(world, merge, group):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "3",
-           "--backend", "gloo", "--check", "--config", "c2", "--merge", merge]
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "7", "--warmup", "5",
+           "--backend", "gloo", "--check", "--config", "c2", "--merge", merge, "--group", str(group)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "check: merged error table == single-pass error table" in r.stderr
