@@ -329,18 +329,21 @@ def main():
                     ctx.set_slice_group(G, i % G)
                     call_part(i, timed, gi % 3)
 
+            # issue order on RCCL's (in-order) stream: all-gather(group - 1) BEFORE the exchange of this group, so that the
+            # poisson_calls of group - 1 do not wait behind this group's reduce-scatter -- in the steady state and,
+            # above all, at the end of the run, where the last exchange then hides behind the previous group's calls
             for gi in range(ngroups):
                 for i in members(gi):
                     ctx.set_slice_group(G, i % G)
                     reduce_part(i, timed, gi % 3)
-                hx[gi] = merger.start_exchange(gi % 3)
                 if gi >= 1:
                     mid(gi - 1)
+                hx[gi] = merger.start_exchange(gi % 3)
                 if gi >= 2:
                     last(gi - 2)
-            mid(ngroups - 1)
             if ngroups >= 2:
                 last(ngroups - 2)
+            mid(ngroups - 1)
             last(ngroups - 1)
             return
         pending = None
