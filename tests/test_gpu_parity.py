@@ -364,6 +364,32 @@ def test_scorer_against_oracle(ctx):
     assert not dis.any() or np.all(np.abs(qo[mq][dis] - 5) < 1e-9)
 
 
+@pytest.mark.skipif(not __import__("os").path.exists(orc.REF_VC_SCORER), reason="oracle/_ref/libvc_scorer_ref.so (the reference's own scorer, built where /root/reference exists) is absent")
+def test_device_scorer_against_the_reference_functions_directly(ctx):
+    """The device scorer against mutationRulesPoissonQualityScore / kf_gammaq themselves (compiled from the reference's
+    source), without the oracle in between: Q within 1e-6 relative wherever it is not clamped, the clamps and special codes
+    identical, and the Q >= 5 decision of VC:898 identical on every point."""
+    import ctypes as C
+
+    R = C.CDLL(orc.REF_VC_SCORER)
+    rng = np.random.default_rng(19)
+    n = 300000
+    k = rng.integers(0, 80, n).astype(np.int32)
+    k[: n // 5] = rng.integers(0, 4000, n // 5)
+    rd = rng.integers(0, 70000, n).astype(np.int32)
+    err = rng.choice(np.array([0.002, 0.01, 0.0005, 0.05, 0.0, -1.0, 0.002189, 0.000123, 0.3, 0.00001], np.float32), n)
+    want = np.empty(n)
+    R.ref_score_batch(k.ctypes.data_as(C.c_void_p), rd.ctypes.data_as(C.c_void_p), err.ctypes.data_as(C.c_void_p), C.c_long(n),
+                      want.ctypes.data_as(C.c_void_p))
+    q, _ = ctx.score_batch(_t(k), _t(rd), _t(err))
+    q = q.cpu().numpy()
+    special = (want == -888.0) | (want == 100.0) | (want == 0.0)
+    assert np.array_equal(q[special], want[special])
+    m = ~special
+    assert np.max(np.abs(q[m] - want[m]) / np.maximum(np.abs(want[m]), 1e-300)) <= Q_TOL
+    assert np.array_equal(q >= 5, want >= 5)
+
+
 @pytest.mark.parametrize("P,T", [(1, 1), (255, 3), (257, 5), (3000, 8)])
 def test_poisson_call_synthetic(ctx, P, T):
     S = 24
