@@ -115,7 +115,7 @@ void parse_file(const Panel &panel, const std::string &path, bool keep_line, Fil
     out.main.assign((size_t)P * 8, 0);
     for (int64_t p = 0; p < P; ++p) out.main[(size_t)p * 8] = AMPLI_ABSENT;
     if (keep_line) out.line.assign((size_t)P, -1);
-    std::vector<uint8_t> occ((size_t)P, 0);
+    std::vector<uint32_t> occ((size_t)P, 0); // occurrences so far of each position in THIS file
 
     const int fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) { out.error = "Cannot open " + path; return; }
@@ -175,8 +175,7 @@ void parse_file(const Panel &panel, const std::string &path, bool keep_line, Fil
                     if (A + C + G + T != RD) { // EE:1178-1181, VC:762-765
                         ++out.n_irregular;
                     }
-                    const unsigned k = occ[pi];
-                    if (k < 255) occ[pi] = (uint8_t)(k + 1);
+                    const uint32_t k = occ[pi]++;
                     if (k == 0) {
                         memcpy(&out.main[(size_t)pi * 8], rec, sizeof rec);
                         if (keep_line) out.line[(size_t)pi] = line_idx;

@@ -70,6 +70,12 @@ struct Dev {
         allocs.push_back(p);
         return (T *)p;
     }
+    void free(void *p)
+    {
+        for (auto it = allocs.begin(); it != allocs.end(); ++it)
+            if (*it == p) { allocs.erase(it); break; }
+        check(api->dev_free(ctx, p), "ampli_dev_free");
+    }
     template <class T> T *upload(const T *src, size_t n)
     {
         T *d = alloc<T>(n ? n : 1);
@@ -324,10 +330,14 @@ int run_variant_calling(const VcArgs &a)
             uint8_t *d_mask = dev.alloc<uint8_t>((size_t)T * R);
             unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
             int64_t cap = std::max<int64_t>(1 << 16, (int64_t)T * R / 16);
-            for (int attempt = 0; attempt < 4; ++attempt) {
+            ampli_call *d_calls = nullptr;
+            bool done = false;
+            std::string why = "call list still overflowing";
+            for (int attempt = 0; attempt < 6 && !done; ++attempt) {
                 cap -= cap % AMPLI_CALL_SHARDS;
                 const int64_t per = cap / AMPLI_CALL_SHARDS;
-                ampli_call *d_calls = dev.alloc<ampli_call>((size_t)cap);
+                if (d_calls) dev.free(d_calls); // the previous attempt's list
+                d_calls = dev.alloc<ampli_call>((size_t)cap);
                 dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
                 dev.check(dev.api->poisson_call(dev.ctx, d_recs, P, co.E, d_ext, T, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask,
                                                 d_calls, cap, d_n, nullptr, nullptr), "ampli_poisson_call");
@@ -335,14 +345,25 @@ int run_variant_calling(const VcArgs &a)
                 dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
                 if (kflags & AMPLI_FLAG_QUEUE_OVERFLOW) { // more survivors than the default queue holds: size it for the worst case
                     dev.check(dev.api->set_queue_items(dev.ctx, (int64_t)T * R * 3), "ampli_set_queue_items");
+                    why = "prefilter queue still overflowing";
                     continue;
                 }
                 std::vector<unsigned long long> n(AMPLI_CALL_COUNTER_WORDS);
                 dev.download(n.data(), d_n, n.size());
                 dev.sync();
-                unsigned long long worst = 0;
-                for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) worst = std::max(worst, n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE]);
-                if ((int64_t)worst > per) { cap = (int64_t)worst * AMPLI_CALL_SHARDS; continue; } // a segment overflowed: rerun, sized for it
+                unsigned long long worst = 0, total = 0;
+                for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
+                    worst = std::max(worst, n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE]);
+                    total += n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
+                }
+                if ((int64_t)worst > per) {
+                    // a segment overflowed.  Which segment a call lands in depends on the order the workgroups ran in, so
+                    // the rerun is sized with headroom: every segment could hold ALL calls of this pass, capped at the
+                    // number of (record, alt) pairs there are
+                    cap = (int64_t)std::min<unsigned long long>((unsigned long long)T * R * 3, std::max(total, 2 * worst)) * AMPLI_CALL_SHARDS;
+                    why = "call list still overflowing";
+                    continue;
+                }
                 for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
                     const size_t cnt = (size_t)n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
                     std::vector<ampli_call> calls(cnt);
@@ -351,8 +372,9 @@ int run_variant_calling(const VcArgs &a)
                     for (auto &c : calls)
                         rows.push_back(CallRow{c.sample, co.line_no[(size_t)c.sample * R + c.record], c.alt, c.record, c.q_fw, c.q_bw, c.af, c.af_fw, c.af_bw});
                 }
-                break;
+                done = true;
             }
+            if (!done) throw Error{AMPLI_E_CAPACITY, "variant calling did not complete a pass: " + why};
         }
         // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
         std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
@@ -438,10 +460,15 @@ int run_variant_calling(const VcArgs &a)
                     const std::string part = summary + ".part" + std::to_string(k);
                     std::ifstream in(part, std::ios::binary);
                     if (!in) throw Error{AMPLI_E_INVALID, "missing Summary part of shard " + std::to_string(k) + " (is output_dir shared by all processes?)"};
-                    all << in.rdbuf();
+                    // an empty part (a shard without calls that is not the header's writer) must not touch `all`:
+                    // operator<<(streambuf*) sets failbit when it inserts nothing and every later part would be lost
+                    if (in.peek() != std::ifstream::traits_type::eof()) all << in.rdbuf();
                     in.close();
+                    if (!all.good()) throw Error{AMPLI_E_INVALID, "could not assemble " + summary + " from the shards' parts"};
                     std::remove(part.c_str());
                 }
+                all.close();
+                if (all.fail()) throw Error{AMPLI_E_INVALID, "could not write " + summary};
             }
         }
         std::cout << "\nAmpliSolveVariantCalling execution was successful. The results can be found at : " << summary << std::endl;

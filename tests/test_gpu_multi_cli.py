@@ -87,6 +87,41 @@ def test_variant_calling_sharded_equals_one_process(tmp_path, world):
     assert os.path.exists(out / "AmpliSolveVariantCalling_interm_files" / "dummyVCF_1.vcf")
 
 
+def test_variant_calling_middle_shard_without_calls(tmp_path):
+    """A shard in the MIDDLE of the visit order whose only tumour file holds no call: its Summary part is empty, and the
+    parts of the shards behind it must still arrive in Summary_Variant_Info.txt (an empty streambuf insert sets failbit)."""
+    import ctypes as C
+    import shutil
+
+    from amplisolve_amd import host_lib
+
+    d = f"{G}/toy_subset"
+    table = f"{d}/expected_positionSpecificNoise_0.0020.txt"
+    td = tmp_path / "TUM"
+    td.mkdir()
+    names = ["KA", "KB", "KC"]
+    for n in names:  # placeholders first: the visit order is a function of the listed path strings only
+        (td / f"{n}.PILEUP.ASEQ").write_text("x\n")
+    buf = C.create_string_buffer(1 << 12)
+    assert host_lib().ampli_host_sample_order(str(td).encode(), buf, len(buf)) == 3
+    order = buf.value.decode().split()
+    header = open(f"{d}/TUMOUR/T1.PILEUP.ASEQ").readline()
+    shutil.copy(f"{d}/TUMOUR/T1.PILEUP.ASEQ", td / f"{order[0]}.PILEUP.ASEQ")
+    (td / f"{order[1]}.PILEUP.ASEQ").write_text(header)  # header only: no line, no call
+    shutil.copy(f"{d}/TUMOUR/T2.PILEUP.ASEQ", td / f"{order[2]}.PILEUP.ASEQ")
+    one = tmp_path / "one"
+    r = subprocess.run([f"{BIN}/AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={td}", f"output_dir={one}",
+                        "coverage_cutoff=100", "p_value=0.05"], capture_output=True, text=True, env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = (one / "Summary_Variant_Info.txt").read_text()
+    samples = [l.split("\t")[0] for l in ref.splitlines()[1:]]
+    assert order[0] in samples and order[2] in samples and order[1] not in samples
+    out = tmp_path / "multi"
+    torchrun(3, 29569, ["AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={td}", f"output_dir={out}",
+                        "coverage_cutoff=100", "p_value=0.05"])
+    assert (out / "Summary_Variant_Info.txt").read_text() == ref
+
+
 def test_failing_shard_ends_the_job(tmp_path):
     """A shard that cannot read its input fails the whole launch promptly (no hang in a collective) with the reason."""
     d = f"{G}/toy_subset"
