@@ -27,8 +27,15 @@ class AccTable(C.Structure):
 
 class Call(C.Structure):
     """mirror of ampli_call"""
-    _fields_ = [("sample", i32), ("record", i32), ("alt", i32), ("pad", i32), ("q_fw", C.c_double),
-                ("q_bw", C.c_double), ("af", f32), ("af_fw", f32), ("af_bw", f32), ("pad2", f32)]
+    _fields_ = [("sample", i32), ("record", i32), ("alt", i32), ("rd", i32), ("q_fw", C.c_double),
+                ("q_bw", C.c_double), ("af", f32), ("af_fw", f32), ("af_bw", f32), ("k_fw", i32), ("k_bw", i32),
+                ("fw", i32), ("bw", i32), ("pad", i32)]
+
+
+class Records(C.Structure):
+    """mirror of ampli_records: a cohort (or a chunk of a streamed one) on the device, described explicitly"""
+    _fields_ = [("recs", vp), ("row_stride", i64), ("ext", vp), ("ext_stride", i64), ("E", i64), ("dup_off", vp),
+                ("ext_pos", vp), ("layout", i32), ("n_samples", i32)]
 
 
 # every symbol include/amplisolve_hip.h declares: (restype, argtypes)
@@ -83,6 +90,9 @@ HIP_SYMBOLS = {
     "ampli_set_tuning": (C.c_int, [vp, i32, i32]),
     "ampli_ctx_flags": (C.c_int, [vp, C.POINTER(i32), i32]),
     "ampli_set_queue_items": (C.c_int, [vp, i64]),
+    "ampli_set_poisson_tuning": (C.c_int, [vp, i32, i32]),
+    "ampli_error_reduce_records": (C.c_int, [vp, C.POINTER(Records), i64, i32, f32, i32, C.POINTER(AccTable), i32, vp, vp, vp, vp, vp, vp]),
+    "ampli_poisson_call_records": (C.c_int, [vp, C.POINTER(Records), i64, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
     "ampli_graph_begin": (C.c_int, [vp]),
     "ampli_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "ampli_graph_launch": (C.c_int, [vp, vp]),
@@ -109,6 +119,7 @@ HOST_SYMBOLS = {
     "ampli_host_af_limit_batch": (None, [vp, i64, vp]),
     "ampli_host_prefilter_nocall": (C.c_int, [i32, i32, f32]),
     "ampli_host_prefilter_skip_f32": (C.c_int, [i32, i32, f32]),
+    "ampli_host_drain_score_batch": (None, [vp, vp, vp, i64, vp, vp]),
     "ampli_host_last_error": (C.c_char_p, []),
     "ampli_host_cohort_load": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
     "ampli_host_cohort_load_shard": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, i32, i32, C.POINTER(vp)]),

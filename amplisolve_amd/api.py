@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
-from ._lib import AccTable, AmpliError, Call, hip_lib
+from ._lib import AccTable, AmpliError, Call, Records, hip_lib
 
 NT = "ACGT"
 POISSON_FULL = 0
@@ -185,6 +185,10 @@ class Context:
     def wait_calls(self):
         self._check(self.lib.ampli_wait_calls(self.h))
 
+    def set_poisson_tuning(self, rows_per_wave: int = 0, drain_blocks: int = 0):
+        """poisson_call launch shape (ampli_set_poisson_tuning); 0 = default.  Results do not depend on it."""
+        self._check(self.lib.ampli_set_poisson_tuning(self.h, rows_per_wave, drain_blocks))
+
     def set_queue_items(self, items: int):
         self._check(self.lib.ampli_set_queue_items(self.h, items))
 
@@ -224,6 +228,46 @@ class Context:
         self._check(self.lib.ampli_error_reduce(self.h, _ptr(recs), P, E, _ptr(dup_off), S, first_sample,
                                                 C_value, cov, C.byref(acc.struct)))
         return acc
+
+    def records(self, recs, layout: str, n_samples: int, E: int = 0, row_stride: int = 0, ext=None, ext_stride: int = 0,
+                dup_off=None, ext_pos=None) -> Records:
+        """ampli_records over device tensors (the caller keeps them alive)."""
+        r = Records(recs.data_ptr(), row_stride, ext.data_ptr() if ext is not None else None, ext_stride, E,
+                    dup_off.data_ptr() if dup_off is not None else None, ext_pos.data_ptr() if ext_pos is not None else None,
+                    self.LAYOUTS[layout], n_samples)
+        r._keep = (recs, ext, dup_off, ext_pos)
+        return r
+
+    def error_reduce_records(self, rec: Records, P: int, acc: Acc | None, C_value: float = 0.002, cov: int = 100, first_sample: int = 0,
+                             accumulate: bool = False, out: ErrorTable | None = None, finalize: bool = False):
+        """One chunk of a cohort into `acc` (accumulate: acc (+) chunk); finalize: also the error table of the merged state."""
+        if finalize and out is None:
+            out = self._new_error_table(P)
+        o = out if finalize else None
+        self._check(self.lib.ampli_error_reduce_records(self.h, C.byref(rec), P, first_sample, C_value, cov,
+                                                        C.byref(acc.struct) if acc is not None else None, int(accumulate),
+                                                        _ptr(o.rate) if o else None, _ptr(o.code) if o else None, _ptr(o.thr) if o else None,
+                                                        _ptr(o.germ_val) if o else None, _ptr(o.germ_present) if o else None,
+                                                        _ptr(o.flags) if o else None))
+        return out
+
+    def poisson_call_records(self, rec: Records, P: int, thr, ref_code, cov: int = 100, mode: int = POISSON_PREFILTER,
+                             call_mask=None, capacity: int = 0, calls_buf=None, n_calls=None):
+        import torch
+
+        T, R = rec.n_samples, P + rec.E
+        d = self.device
+        if call_mask is None:
+            call_mask = torch.empty(((T * R + 3) // 4 * 4,), dtype=torch.uint8, device=d)[: T * R].view(T, R)
+        if capacity > 0 and calls_buf is None:
+            calls_buf = torch.empty((capacity * C.sizeof(Call),), dtype=torch.uint8, device=d)
+        if capacity > 0:
+            capacity -= capacity % CALL_SHARDS
+        if (capacity > 0 or n_calls is not None) and n_calls is None:
+            n_calls = torch.zeros((CALL_COUNTER_WORDS,), dtype=torch.int64, device=d)
+        self._check(self.lib.ampli_poisson_call_records(self.h, C.byref(rec), P, _ptr(thr), _ptr(ref_code), cov, mode, _ptr(call_mask),
+                                                        _ptr(calls_buf), capacity, _ptr(n_calls), None, None))
+        return dict(call_mask=call_mask, q=None, af=None, calls_buf=calls_buf, n_calls=n_calls, capacity=capacity)
 
     def _new_error_table(self, P: int) -> ErrorTable:
         import torch
@@ -373,8 +417,10 @@ class Context:
             raise AmpliError(f"call list segment overflowed: {int(counts.max())} > {per}; rerun with a larger capacity")
         sz = C.sizeof(Call)
         raw = b"".join(res["calls_buf"][k * per * sz: (k * per + int(counts[k])) * sz].cpu().numpy().tobytes() for k in range(CALL_SHARDS))
-        dt = np.dtype([("sample", "<i4"), ("record", "<i4"), ("alt", "<i4"), ("pad", "<i4"), ("q_fw", "<f8"),
-                       ("q_bw", "<f8"), ("af", "<f4"), ("af_fw", "<f4"), ("af_bw", "<f4"), ("pad2", "<f4")])
+        dt = np.dtype([("sample", "<i4"), ("record", "<i4"), ("alt", "<i4"), ("rd", "<i4"), ("q_fw", "<f8"),
+                       ("q_bw", "<f8"), ("af", "<f4"), ("af_fw", "<f4"), ("af_bw", "<f4"), ("k_fw", "<i4"), ("k_bw", "<i4"),
+                       ("fw", "<i4"), ("bw", "<i4"), ("pad", "<i4")])
+        assert dt.itemsize == sz
         a = np.frombuffer(raw, dtype=dt)
         a = a[np.lexsort((a["alt"], a["record"], a["sample"]))]
         return a

@@ -53,6 +53,8 @@ struct ampli_ctx {
     hipEvent_t ev_stream_done = nullptr, ev_drain_done = nullptr;
     bool drain_pending = false;
     int n_cu = 256;
+    // poisson_call tuning (ampli_set_poisson_tuning; 0 = default)
+    int pc_rows_per_wave = 0, pc_drain_blocks = 0;
 };
 
 #define HIP_TRY(ctx, expr)                                                                        \
@@ -313,6 +315,14 @@ extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, in
     return AMPLI_OK;
 }
 
+extern "C" int ampli_set_poisson_tuning(ampli_ctx *ctx, int32_t rows_per_wave, int32_t drain_blocks_per_shard)
+{
+    if (!ctx || rows_per_wave < 0 || drain_blocks_per_shard < 0 || drain_blocks_per_shard > 65535) return AMPLI_E_INVALID;
+    ctx->pc_rows_per_wave = rows_per_wave;
+    ctx->pc_drain_blocks = drain_blocks_per_shard;
+    return AMPLI_OK;
+}
+
 extern "C" int ampli_set_queue_items(ampli_ctx *ctx, int64_t items)
 {
     if (!ctx || items < 0) return AMPLI_E_INVALID;
@@ -364,6 +374,36 @@ template <int LAY> __device__ __forceinline__ RawRec<LAY> rec_load(const int4 *_
         r.a = ld_stream(recs + index); r.b = r.a;
     } else {
         r.a = ld_stream(recs + index * 2); r.b = ld_stream(recs + index * 2 + 1);
+    }
+    return r;
+}
+
+// A cohort (or one chunk of a streamed cohort) on the device.  Record r < P of sample s lives at
+// base + (s*row_stride + r) * record_bytes; extra occurrence e (record P + e) at ext + (s*ext_stride + e) * record_bytes.
+// The dense interchange layout [n][P+E] is row_stride = ext_stride = P + E, ext = base + P records; a padded row stride
+// (power-of-two panels) or a separately uploaded extras array are the same kernels with other numbers.
+struct RecView {
+    const char *base;
+    long long row_stride; // records
+    const char *ext;
+    long long ext_stride; // records
+};
+
+template <int LAY> __host__ __device__ constexpr int rec_bytes_of()
+{
+    return LAY == AMPLI_RECORDS_U24 ? 24 : (LAY == AMPLI_RECORDS_U16 ? 16 : 32);
+}
+
+template <int LAY> __device__ __forceinline__ RawRec<LAY> rec_load_at(const char *__restrict__ q)
+{
+    RawRec<LAY> r;
+    if constexpr (LAY == AMPLI_RECORDS_U24) {
+        const uint2 *__restrict__ u = (const uint2 *)q;
+        r.a = u[0]; r.b = u[1]; r.c = u[2];
+    } else if constexpr (LAY == AMPLI_RECORDS_U16) {
+        r.a = ld_stream((const int4 *)q); r.b = r.a;
+    } else {
+        r.a = ld_stream((const int4 *)q); r.b = ld_stream((const int4 *)q + 1);
     }
     return r;
 }
@@ -603,6 +643,8 @@ struct FinOut {
     float *sl_gm;        // [n_slices][8][slice_len]: germ-max first_af[4] (-1 = no qualifying record) | rest[4]
     long long sl_group;  // batches per slice chunk (ampli_set_slice_group): chunk k of this batch starts k*sl_group*{21,8}*slice_len
                          //  elements behind sl_sums / sl_gm (which already point at this batch's part of chunk 0)
+    int accumulate;      // the table already holds the state of the EARLIER samples: result = table (+) this launch
+                         //  (streamed cohorts: one launch per uploaded chunk of samples, in visit order)
 };
 
 __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, const long long P, const long long p, const LaneAcc &a)
@@ -908,7 +950,7 @@ __device__ __forceinline__ void lane_acc_shfl_down(const LaneAcc &a, LaneAcc &b,
 // at G = 1 shrinks with the wave lifetime).  A lane group still reads >= 512 contiguous bytes per sample row.
 template <bool FAST, int G, int LAY>
 __global__ __launch_bounds__(256) void error_reduce_kernel(
-    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ dup_off,
+    const RecView rv, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
     const size_t part_stride, const size_t o0, const size_t o1, const size_t o2, const size_t o3, const size_t o4,
     const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags, const FinOut fin)
@@ -921,7 +963,6 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     const long long p_raw = (long long)blockIdx.x * W + (lane % W);
     const bool valid = p_raw < P;
     const long long p = valid ? p_raw : P - 1; // clamp: out-of-range lanes re-read the last position, never store
-    const long long R = P + E;
     const int chunk = (blockIdx.y * RED_WAVES + wave) * G + group;
     const int s0 = min(S, chunk * chunk_len);
     const int s1 = min(S, s0 + chunk_len);
@@ -937,16 +978,17 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
 
     // one sample row in registers + the next one in flight; every lane group walks its own chunk, the trip count
     // (chunk_len) is wave-uniform and rows past a group's chunk are loaded clamped and not visited
-    const size_t row_stride = (size_t)R; // in records
-    size_t qi = (size_t)min(s0, S - 1) * R + p;
-    RawRec<LAY> nx = rec_load<LAY>(recs, qi);
+    constexpr int RB = rec_bytes_of<LAY>();
+    const size_t row_step = (size_t)rv.row_stride * RB; // bytes between the same position of consecutive samples
+    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;
+    RawRec<LAY> nx = rec_load_at<LAY>(q);
     for (int i = 0; i < chunk_len; ++i) {
         const int s = s0 + i;
         int4 c0, c1;
         rec_decode<LAY>(nx, c0, c1);
         if (i + 1 < chunk_len) { // prefetch while this row is consumed
-            if (s + 1 < S) qi += row_stride;
-            nx = rec_load<LAY>(recs, qi);
+            if (s + 1 < S) q += row_step;
+            nx = rec_load_at<LAY>(q);
         }
         if (s < s1) {
             // G == 1: s0 / s1 are wave-uniform, the whole wave is here -> the lean Germ_Max path.  Only the 16-byte
@@ -956,7 +998,7 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
             if (any_dup) { // extras of this position in the same sample, in file order
                 for (unsigned e = e0; e < e1; ++e) {
                     int4 x0, x1;
-                    rec_decode<LAY>(rec_load<LAY>(recs, (size_t)s * R + (size_t)P + e), x0, x1);
+                    rec_decode<LAY>(rec_load_at<LAY>(rv.ext + ((size_t)s * (size_t)rv.ext_stride + e) * RB), x0, x1);
                     if (FAST) visit_fast<false>(f, x0, x1, first_sample + s, C, cov); // per-lane trip counts: no wave-level shortcuts
                     else visit_record(a, x0, x1, first_sample + s, C, cov);
                 }
@@ -996,6 +1038,12 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
         lds_get(sh, 0, lane, b);
         lane_acc_merge(a, b);
         if (valid && group == 0) {
+            if (fin.accumulate) { // earlier chunks of the cohort (+) this one; never with sample splits (host folds those)
+                LaneAcc prior;
+                lane_acc_load(acc_at(out_base, P, o0, o1, o2, o3, o4, o5, o6, o7), P, p_raw, prior);
+                lane_acc_merge(prior, a);
+                a = prior;
+            }
             if (out_base) {
                 const AccPtrs t = acc_at(out_base + (size_t)blockIdx.y * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7);
                 if (fin.packed) { // multi-GPU shard: sums straight into the all-reduce buffer, table keeps the gm planes
@@ -1019,13 +1067,14 @@ __global__ __launch_bounds__(256) void acc_merge_kernel(char *dst_base, const ch
                                                         const int nparts, const long long P, const size_t o0,
                                                         const size_t o1, const size_t o2, const size_t o3,
                                                         const size_t o4, const size_t o5, const size_t o6,
-                                                        const size_t o7)
+                                                        const size_t o7, const char *prior_base)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= P) return;
     LaneAcc a;
-    lane_acc_load(acc_at(const_cast<char *>(parts_base), P, o0, o1, o2, o3, o4, o5, o6, o7), P, p, a);
-    for (int i = 1; i < nparts; ++i) {
+    // prior_base: a table holding the state of earlier samples (streamed cohorts); the parts follow it in order
+    lane_acc_load(acc_at(const_cast<char *>(prior_base ? prior_base : parts_base), P, o0, o1, o2, o3, o4, o5, o6, o7), P, p, a);
+    for (int i = prior_base ? 0 : 1; i < nparts; ++i) {
         LaneAcc b;
         lane_acc_load(acc_at(const_cast<char *>(parts_base) + (size_t)i * part_stride, P, o0, o1, o2, o3, o4, o5, o6, o7), P, p, b);
         lane_acc_merge(a, b);
@@ -1264,14 +1313,27 @@ __device__ __forceinline__ float thr_at(const float *__restrict__ thr, const lon
     return ((const float *)((const char *)thr + (size_t)k * block_bytes + (size_t)slice_len * 32))[j * slice_len + q];
 }
 
+// the reported VAFs and the evidence of one emitted call (VC:772-817)
+__device__ __forceinline__ void call_fill(ampli_call &c, const int sample, const int record, const int alt, const int rd, const double q_fw,
+                                          const double q_bw, const int k_fw, const int k_bw, const int FW, const int BW)
+{
+    c.sample = sample; c.record = record; c.alt = alt; c.rd = rd;
+    c.q_fw = q_fw; c.q_bw = q_bw;
+    c.af = (float)(k_fw + k_bw) / (float)rd;               // VC:814-817
+    c.af_fw = FW == 0 ? 0.0f : (float)k_fw / (float)FW;    // VC:785-790
+    c.af_bw = BW == 0 ? 0.0f : (float)k_bw / (float)BW;    // VC:805-810
+    c.k_fw = k_fw; c.k_bw = k_bw; c.fw = FW; c.bw = BW; c.pad = 0;
+}
+
 template <int MODE, int LAY>
 __global__ __launch_bounds__(256) void poisson_call_kernel(
-    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
+    const RecView rv, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
     const unsigned char *__restrict__ ref_code, const int cov,
     unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
     unsigned long long *__restrict__ n_calls, double *__restrict__ qd, float *__restrict__ afd)
 {
+    constexpr int RB = rec_bytes_of<LAY>();
     const long long R = P + E;
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
@@ -1288,8 +1350,10 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
         const int t = t0 + dt;
         if (t >= T) break;
         const size_t o = (size_t)t * R + r;
+        const char *q = r < P ? rv.base + ((size_t)t * (size_t)rv.row_stride + (size_t)r) * RB
+                              : rv.ext + ((size_t)t * (size_t)rv.ext_stride + (size_t)(r - P)) * RB;
         int4 r0, r1;
-        rec_decode<LAY>(rec_load<LAY>(recs, o), r0, r1);
+        rec_decode<LAY>(rec_load_at<LAY>(q), r0, r1);
         const bool present = r0.x != AMPLI_ABSENT;
         const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
         const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
@@ -1334,12 +1398,7 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
                         const long long idx = call_slot(n_calls, capacity);
                         if (calls && idx >= 0) {
                             ampli_call c;
-                            c.sample = t; c.record = (int)r; c.alt = nt; c.pad = 0;
-                            c.q_fw = q_fw; c.q_bw = q_bw;
-                            c.af = (float)(fw[nt] + bw[nt]) / (float)RD;          // VC:814-817
-                            c.af_fw = FW == 0 ? 0.0f : (float)fw[nt] / (float)FW; // VC:785-790
-                            c.af_bw = BW == 0 ? 0.0f : (float)bw[nt] / (float)BW; // VC:805-810
-                            c.pad2 = 0.0f;
+                            call_fill(c, t, (int)r, nt, RD, q_fw, q_bw, k_fw, k_bw, FW, BW);
                             calls[idx] = c;
                         }
                     }
@@ -1353,70 +1412,68 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 // ---------------------------------------------------------------------------
 // poisson_call, prefilter mode = two kernels.
 //
-// poisson_stream_kernel: one lane per position, a few tumour rows per workgroup; thresholds, reference
-//   code and the derived per-position constants stay in registers across the rows.  Most (record, alt) pairs are
-//   settled by a conservative fp32 form of the exact bound "k <= m = RD*err => Q < 5" (ampli_prefilter_nocall):
-//       skip  <=>  float(k) <= (float(RD) * 0.999999f) * err_eff
+// poisson_stream_kernel: one lane per record, one WAVE per (64-record tile, group of tumour rows); the four waves of a
+//   workgroup take four consecutive row groups of the same tile, so the tile's thresholds / reference codes (33 B per
+//   position) are fetched once per workgroup and hit L1/L2 for the other three waves, and the workgroups of one tile
+//   are dealt to ONE XCD (blockIdx -> (tile, row group) mapping below) so that they share that XCD's L2 copy: the
+//   thresholds cross the fabric about once per launch instead of once per four rows.
+//   Most (record, alt) pairs are settled by a conservative fp32 form of the exact bound "k <= m = RD*err => Q < 5"
+//   (ampli_prefilter_nocall):       skip  <=>  float(k) <= (float(RD) * 0.999999f) * err_eff
 //   which implies k < m (both operands are exact floats below 2^24 and the product is rounded below RD*err), with
 //   err_eff = +inf for err == -1 (Q = -888) and 0.0010008f for err == 0.  Anything not provably skippable -- real
 //   variants, noisy cells, the rounding fringe: ~0.2 % of the records -- is appended to a queue in HBM.
-// poisson_drain_kernel: evaluates the queue DENSELY, two adjacent lanes per item (one per strand) with the full
-//   kf scorer, ORs the call bits into the mask and appends the compact call records.
+// poisson_drain_kernel<LPS>: evaluates the queue DENSELY with the kf scorer, LPS lanes per (item, strand); ORs the
+//   call bits into the mask and appends the compact call records.
 //
 // Evaluating survivors in place would stall 63 lanes behind one ~100-iteration fp64 loop; draining per wave from
-// LDS (an earlier version) still paid one such loop per wave for a couple of items.  The dense second kernel pays
-// it once per 32 items.
+// LDS (an earlier version) still paid one such loop per wave for a couple of items.
 // ---------------------------------------------------------------------------
 
-struct PcItem { // 32 bytes, self-contained: the drain kernel needs no second look at the records or the thresholds
+struct PcItem { // 40 bytes, self-contained: the drain kernel needs no second look at the records or the thresholds
     int sample;
-    int record_alt;             // record | alt << 30
-    int k_fw, d_fw, k_bw, d_bw; // VC:895-896 arguments (d_fw = RD - BW)
-    float e_fw, e_bw;           // effective errors (ampli_effective_err)
+    int record_alt;   // record | alt << 30
+    int k_fw, k_bw;   // alt reads per strand
+    int FW, BW;       // strand depths
+    int rd;           // RD column: d_fw = rd - BW (VC:895), AF = X / rd (VC:814)
+    float e_fw, e_bw; // effective errors (ampli_effective_err)
+    int pad;
 };
+
+// blockIdx.x -> (tile, row group): workgroups are dealt round-robin to the 8 XCDs (b and b + 8 share one), so the
+// row groups of a tile are given consecutive slots of ONE XCD.  tiles8 = tiles rounded up to a multiple of 8.
+__device__ __forceinline__ void pc_block_map(const unsigned b, const unsigned gy, unsigned &tile, unsigned &y)
+{
+    const unsigned xcd = b & 7u, slot = b >> 3;
+    tile = (slot / gy) * 8u + xcd;
+    y = slot % gy;
+}
 
 template <int LAY>
 __global__ __launch_bounds__(256) void poisson_stream_kernel(
-    const int4 *__restrict__ recs, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
-    const int T, const int rows_per_block, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
+    const RecView rv, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
+    const int T, const int rows_per_wave, const unsigned gy, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
     const unsigned char *__restrict__ ref_code,
     const int cov, PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
-    unsigned *__restrict__ mask_words, int *__restrict__ flags, unsigned long long *__restrict__ n_calls)
+    unsigned char *__restrict__ call_mask, int *__restrict__ flags, unsigned long long *__restrict__ n_calls)
 {
+    constexpr int RB = rec_bytes_of<LAY>();
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long R = P + E;
     // the call-list counters are reset here: only the drain kernel, which starts after this one has finished,
     // appends to the list
-    if (n_calls && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < AMPLI_CALL_SHARDS)
-        n_calls[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
-    const long long r_raw = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n_calls && blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) n_calls[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
+    unsigned tile, y;
+    pc_block_map(blockIdx.x, gy, tile, y);
+    const long long r_raw = (long long)tile * 64 + lane;
+    if ((long long)tile * 64 >= R) return; // padding workgroups of the XCD mapping
     const bool valid = r_raw < R;
     const long long r = valid ? r_raw : R - 1;
     const long long p = r < P ? r : (long long)ext_pos[r - P];
-    const int t0 = blockIdx.y * rows_per_block;
-    const int nt_rows = min(rows_per_block, T - t0);
+    const int t0 = ((int)y * 4 + wave) * rows_per_wave; // this wave's run of rows
+    const int nt_rows = min(rows_per_wave, T - t0);
+    if (nt_rows <= 0) return;
     const int ref = valid ? (int)ref_code[p] : 255;
-
-    // this workgroup's slice of the call mask starts as "no call": rows [t0, t0+nt_rows) x 256 records, whole
-    // words only (R is a multiple of 4 here or the tail word is shared with the next row and zeroed by both).
-    {
-#if defined(AMPLI_DIAG_NOMASK)
-        for (int i = threadIdx.x; i < nt_rows * 64 && P < 0; i += 256) {
-#else
-        for (int i = threadIdx.x; i < nt_rows * 64; i += 256) {
-#endif
-            const int dt = i >> 6, w = i & 63;
-            const long long rec = (long long)blockIdx.x * 256 + (long long)w * 4;
-            if (rec < R) {
-                const size_t byte = (size_t)(t0 + dt) * R + rec;
-                if ((R & 3) == 0) mask_words[byte >> 2] = 0u;
-                else { // unaligned rows: byte stores for this rare shape
-                    unsigned char *mb = (unsigned char *)mask_words;
-                    for (int j = 0; j < 4 && rec + j < R; ++j) mb[byte + j] = 0;
-                }
-            }
-        }
-    }
 
     float te[2][4]; // effective error per strand / nucleotide
 #pragma unroll
@@ -1426,17 +1483,21 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
             te[st][nt] = ampli_effective_err(thr_at(thr, P, thr_L, thr_bb, st * 4 + nt, p)); // VC:887-890
         }
     }
-    const unsigned shard = (blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS; // workgroups dealt round-robin
+    const unsigned shard = blockIdx.x % AMPLI_CALL_SHARDS;
 
-    size_t ri = (size_t)t0 * R + r; // record index
-    RawRec<LAY> nx = rec_load<LAY>(recs, ri);
+    const size_t step = (size_t)(r < P ? rv.row_stride : rv.ext_stride) * RB; // bytes between consecutive samples
+    const char *__restrict__ q = r < P ? rv.base + ((size_t)t0 * (size_t)rv.row_stride + (size_t)r) * RB
+                                       : rv.ext + ((size_t)t0 * (size_t)rv.ext_stride + (size_t)(r - P)) * RB;
+    unsigned char *__restrict__ mrow = call_mask + (size_t)t0 * R + r;
+    RawRec<LAY> nx = rec_load_at<LAY>(q);
     for (int dt = 0; dt < nt_rows; ++dt) {
         int4 r0v, r1v;
         rec_decode<LAY>(nx, r0v, r1v);
         if (dt + 1 < nt_rows) { // prefetch the next sample row
-            ri += (size_t)R;
-            nx = rec_load<LAY>(recs, ri);
+            q += step;
+            nx = rec_load_at<LAY>(q);
         }
+        if (valid) mrow[(size_t)dt * R] = 0; // this record's byte of the call mask starts as "no call" (the drain ORs bits in)
         const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
         const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
         const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
@@ -1453,11 +1514,7 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
         for (int nt = 0; nt < 4; ++nt) {
             const bool skip_fw = exact && (unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)fw[nt] <= c_fw * te[0][nt];
             const bool skip_bw = exact && (unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)bw[nt] <= c_bw * te[1][nt];
-#if defined(AMPLI_DIAG_NOPUSH)
-            if (live && nt != ref && !skip_fw && !skip_bw && fw[nt] == -12345) pushmask |= 1u << nt;
-#else
             if (live && nt != ref && !skip_fw && !skip_bw) pushmask |= 1u << nt;
-#endif
         }
         if (__any(pushmask != 0)) { // rare
 #pragma unroll
@@ -1476,8 +1533,8 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
                         if (i < queue_per_shard) {
                             PcItem it;
                             it.sample = t0 + dt; it.record_alt = (int)r | (nt << 30);
-                            it.k_fw = fw[nt]; it.d_fw = d_fw; it.k_bw = bw[nt]; it.d_bw = d_bw;
-                            it.e_fw = te[0][nt]; it.e_bw = te[1][nt];
+                            it.k_fw = fw[nt]; it.k_bw = bw[nt]; it.FW = FW; it.BW = BW; it.rd = RD;
+                            it.e_fw = te[0][nt]; it.e_bw = te[1][nt]; it.pad = 0;
                             queue[(size_t)shard * queue_per_shard + i] = it;
                         } else {
                             atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
@@ -1489,69 +1546,62 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     }
 }
 
+// Two adjacent lanes per queued item, one per strand.  The scorer here is kf_gammaq's series branch in its
+// division-free form (ampli_kf_gammap_series_nodiv): a queued item has k > m on both strands or is no call.
 __global__ __launch_bounds__(256) void poisson_drain_kernel(
     const PcItem *__restrict__ queue, const long long queue_per_shard, const unsigned long long *__restrict__ queue_n,
     const long long R, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls, const long long capacity,
     unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n)
 {
+    constexpr int IPB = 128; // items per workgroup pass
     // the counter array of the NEXT poisson_call (the other half of a double buffer; its last reader, the previous
     // drain, finished before this kernel started) is reset here, which saves a memset launch per call
-    if (blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) next_queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
-    const long long nthreads = (long long)gridDim.x * blockDim.x;
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    // the shards form one flat index space: cum[k] = items in shards < k (clamped to the segment size)
-    __shared__ long long cum[AMPLI_CALL_SHARDS + 1];
-    __shared__ long long cnt[AMPLI_CALL_SHARDS];
-    if (threadIdx.x < AMPLI_CALL_SHARDS) { // 32 independent loads in flight at once, not a serial chain of them
-        const long long n = (long long)queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE];
-        cnt[threadIdx.x] = n > queue_per_shard ? queue_per_shard : n;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long c = 0;
-        for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) { cum[k] = c; c += cnt[k]; }
-        cum[AMPLI_CALL_SHARDS] = c;
-    }
-    __syncthreads();
-    const long long n_evals = 2 * cum[AMPLI_CALL_SHARDS];
-    {
-        // two adjacent lanes per item; the loop runs in whole waves so that a pair is always together
-        for (long long base = (tid & ~63ll); base < n_evals; base += nthreads) {
-            const long long e = base + (tid & 63);
-            const bool on = e < n_evals;
-            double qv = 0.0;
-            PcItem it;
-            int strand = (int)(e & 1);
-            if (on) {
-                const long long g = e >> 1;
-                int shard = 0;
-#pragma unroll
-                for (int step = AMPLI_CALL_SHARDS / 2; step > 0; step >>= 1)
-                    if (cum[shard + step] <= g) shard += step;
-                it = queue[(size_t)shard * queue_per_shard + (g - cum[shard])];
-                const float err = strand ? it.e_bw : it.e_fw;
-                // err_eff = +inf stands for err == -1 (Q = -888, VC:3844-3849); 0 was already replaced by 0.0010008f
-                qv = isinf(err) ? -888.0 : ampli_poisson_score(strand ? it.k_bw : it.k_fw, strand ? it.d_bw : it.d_fw, err); // VC:895-896
-            }
-            const double q_other = __shfl_xor(qv, 1);
-            if (on && strand == 0 && qv >= 5 && q_other >= 5) { // VC:898 (coverage was checked before queueing)
-                const int record = it.record_alt & 0x3FFFFFFF, alt = (it.record_alt >> 30) & 3;
-                const size_t o = (size_t)it.sample * R + record;
-                atomicOr(&mask_words[o >> 2], (1u << alt) << ((o & 3) * 8));
-                if (n_calls) {
-                    const unsigned cs = (unsigned)(blockIdx.x % AMPLI_CALL_SHARDS);
-                    const long long per = capacity / AMPLI_CALL_SHARDS;
-                    const unsigned long long i = atomicAdd(&n_calls[cs * AMPLI_CALL_COUNTER_STRIDE], 1ull);
-                    if (calls && (long long)i < per) {
-                        const int FW = it.d_fw, BW = it.d_bw; // RD = FW + BW (include/amplisolve_hip.h)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < AMPLI_CALL_SHARDS) next_queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
+    // blockIdx.x = queue shard, blockIdx.y = workgroup within the shard: one load tells a workgroup what is its to do
+    const unsigned shard = blockIdx.x;
+    long long cnt = (long long)queue_n[shard * AMPLI_CALL_COUNTER_STRIDE];
+    if (cnt > queue_per_shard) cnt = queue_per_shard;
+    const int slot = threadIdx.x >> 1, strand = threadIdx.x & 1;
+    for (long long ib = (long long)blockIdx.y * IPB; ib < cnt; ib += (long long)gridDim.y * IPB) {
+        const long long i = ib + slot;
+        const bool on = i < cnt;
+        PcItem it = queue[(size_t)shard * queue_per_shard + (on ? i : ib)];
+        const int k = strand ? it.k_bw : it.k_fw;
+        const int d = strand ? it.BW : it.rd - it.BW; // VC:895-896
+        const float err = strand ? it.e_bw : it.e_fw;
+        // err_eff = +inf stands for err == -1 (Q = -888, VC:3844-3849); 0 was already replaced by 0.0010008f.
+        // k <= m: the exact form of the prefilter bound (ampli_prefilter_nocall), Q < 5 -- no call whatever the value.
+        const double m = (double)d * err; // VC:3864: double * float
+        const bool eval = on && !isinf(err) && (double)k > m; // then z = m < s = k: the series branch of kf_gammaq (VC:3728)
+        double qv = -1.0; // "no call" (any value below 5)
+        if (eval) {
+            if (m > 0) qv = ampli_q_from_p(1 - (1. - ampli_kf_gammap_series_nodiv((double)k, m))); // VC:3865 on top of VC:3728: p = 1 - (1 - P(s, z))
+            else if (m == 0) qv = 100.0; // z = 0: the reference's series gives P = exp(-inf) = 0, p = 0 < 1e-10
+            // m < 0 (a negative error cell, or an irregular line with RD < RD_reverse): log(z) is NaN in the reference,
+            // Q is NaN and VC:898 is false
+        }
+        const double q_other = __shfl_xor(qv, 1);
+        const bool emit = on && strand == 0 && qv >= 5 && q_other >= 5; // VC:898 (coverage was checked before queueing)
+        if (emit) {
+            const int record = it.record_alt & 0x3FFFFFFF, alt = (it.record_alt >> 30) & 3;
+            const size_t o = (size_t)it.sample * R + record;
+            atomicOr(&mask_words[o >> 2], (1u << alt) << ((o & 3) * 8));
+        }
+        if (n_calls) { // one counter add per wave, not per call
+            const unsigned long long bal = __ballot(emit);
+            if (bal) {
+                const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)bal) - 1;
+                const unsigned cs = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS);
+                const long long per = capacity / AMPLI_CALL_SHARDS;
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(&n_calls[cs * AMPLI_CALL_COUNTER_STRIDE], (unsigned long long)__popcll(bal));
+                base = __shfl(base, leader);
+                if (emit && calls) {
+                    const long long idx = (long long)base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
+                    if (idx < per) {
                         ampli_call c;
-                        c.sample = it.sample; c.record = record; c.alt = alt; c.pad = 0;
-                        c.q_fw = qv; c.q_bw = q_other;
-                        c.af = (float)(it.k_fw + it.k_bw) / (float)(FW + BW);   // VC:814-817
-                        c.af_fw = FW == 0 ? 0.0f : (float)it.k_fw / (float)FW;  // VC:785-790
-                        c.af_bw = BW == 0 ? 0.0f : (float)it.k_bw / (float)BW;  // VC:805-810
-                        c.pad2 = 0.0f;
-                        calls[(size_t)cs * per + i] = c;
+                        call_fill(c, it.sample, it.record_alt & 0x3FFFFFFF, (it.record_alt >> 30) & 3, it.rd, qv, q_other, it.k_fw, it.k_bw, it.FW, it.BW);
+                        calls[(size_t)cs * per + idx] = c;
                     }
                 }
             }
@@ -1686,18 +1736,73 @@ static int launch_finalize(ampli_ctx *ctx, const AccPtrs &t, long long P, float 
     return check_launch(ctx, "error_finalize_kernel");
 }
 
+// what the kernels read: a cohort (or one chunk of a streamed one) resident on the device
+struct DevCohort {
+    RecView rv;
+    int layout;   // AMPLI_RECORDS_*
+    int n;        // samples
+    long long E;  // extra-occurrence slots per sample
+    const unsigned *dup_off; // [P+1]: extras of position p are e in [dup_off[p], dup_off[p+1])   (error_reduce)
+    const unsigned *ext_pos; // [E]: position of extra e                                          (poisson_call)
+};
+
+static size_t rec_bytes_rt(int layout) { return layout == AMPLI_RECORDS_U24 ? 24 : (layout == AMPLI_RECORDS_U16 ? 16 : 32); }
+
+// the dense interchange layout [n][P+E] in the context's record layout (the classic entry points)
+static DevCohort dense_cohort(const ampli_ctx *ctx, const void *d_recs, int64_t P, int64_t E, int n, const uint32_t *dup_off,
+                              const uint32_t *ext_pos)
+{
+    DevCohort c;
+    c.layout = ctx->rec_layout;
+    c.rv.base = (const char *)d_recs;
+    c.rv.row_stride = P + E;
+    c.rv.ext = (const char *)d_recs + (size_t)P * rec_bytes_rt(c.layout);
+    c.rv.ext_stride = P + E;
+    c.n = n; c.E = E; c.dup_off = dup_off; c.ext_pos = ext_pos;
+    return c;
+}
+
+static int cohort_from_records(ampli_ctx *ctx, const ampli_records *r, int64_t P, DevCohort &c)
+{
+    if (!r || !r->recs || r->n_samples <= 0 || r->E < 0) return fail(ctx, AMPLI_E_INVALID, "records: recs, n_samples > 0 and E >= 0 are required");
+    if (r->layout != AMPLI_RECORDS_I32 && r->layout != AMPLI_RECORDS_U16 && r->layout != AMPLI_RECORDS_U24)
+        return fail(ctx, AMPLI_E_INVALID, "records: unknown layout");
+    c.layout = r->layout;
+    c.n = r->n_samples;
+    c.E = r->E;
+    c.dup_off = r->dup_off; c.ext_pos = r->ext_pos;
+    c.rv.base = (const char *)r->recs;
+    c.rv.row_stride = r->row_stride > 0 ? r->row_stride : (r->ext ? P : P + r->E);
+    if (r->ext) {
+        c.rv.ext = (const char *)r->ext;
+        c.rv.ext_stride = r->ext_stride > 0 ? r->ext_stride : r->E;
+        if (c.rv.row_stride < P || c.rv.ext_stride < r->E) return fail(ctx, AMPLI_E_INVALID, "records: row_stride < P or ext_stride < E");
+    } else {
+        c.rv.ext = c.rv.base + (size_t)P * rec_bytes_rt(c.layout);
+        c.rv.ext_stride = c.rv.row_stride;
+        if (c.rv.row_stride < P + r->E) return fail(ctx, AMPLI_E_INVALID, "records: row_stride < P + E");
+    }
+    return AMPLI_OK;
+}
+
 // reduce (+ optional fused finalize).  d_acc may be NULL when fin.rate is set (the table is then not materialised
 // unless the sample axis has to be split across workgroups).
-static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
-                             int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc,
-                             const FinOut &fin)
+static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int32_t first_sample, float C, int32_t cov,
+                             const ampli_acc_table *d_acc, const FinOut &fin)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (!d_recs || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate && !fin.slice_len) || (fin.packed && !d_acc))
+    const int64_t E = co.E;
+    const int32_t S = co.n;
+    const uint32_t *d_dup_off = co.dup_off;
+    if (!co.rv.base || P <= 0 || E < 0 || S <= 0 || cov < 1 || (d_acc && (!acc_is_bound(d_acc) || d_acc->P != P)) || (!d_acc && !fin.rate && !fin.slice_len) || (fin.packed && !d_acc))
         return fail(ctx, AMPLI_E_INVALID, "error_reduce: bad argument (P,S>0, cov>=1, table bound with ampli_acc_bind for the same P)");
+    if (fin.accumulate && !d_acc) return fail(ctx, AMPLI_E_INVALID, "error_reduce: accumulate needs the table");
     if (E > 0 && !d_dup_off) return fail(ctx, AMPLI_E_INVALID, "error_reduce: E > 0 needs dup_off");
-    if (((uintptr_t)d_recs & (ctx->rec_layout == AMPLI_RECORDS_U24 ? 7 : 15)) != 0)
-        return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
+    {
+        const uintptr_t am = co.layout == AMPLI_RECORDS_U24 ? 7 : 15;
+        if (((uintptr_t)co.rv.base & am) != 0 || (E > 0 && ((uintptr_t)co.rv.ext & am) != 0))
+            return fail(ctx, AMPLI_E_INVALID, "error_reduce: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
 
     // lane groups per wave: only for panels too small to fill the chip with 64-position waves (measured on c3:
@@ -1741,17 +1846,18 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         kfin.rate = nullptr;
         kfin.packed = nullptr; // packed after the merge, below
         kfin.slice_len = 0;
+        kfin.accumulate = 0;   // folded in by the merge kernel, below
     }
     if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE_L(FASTV, GV, UV)                                                                                      \
-    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_recs, (long long)P, \
+    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P, \
                        (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],  \
                        off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin)
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                           \
     do {                                                         \
-        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U24);      \
-        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U16); \
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U24);      \
+        else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U16); \
         else AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_I32);                                           \
     } while (0)
     if (fast) {
@@ -1771,7 +1877,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, i
         char *merged = d_acc ? (char *)d_acc->snt : (char *)ctx->ws + off[8] * (size_t)splits;
         hipLaunchKernelGGL(acc_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, merged,
                            (const char *)ctx->ws, stride, splits, (long long)P, off[0], off[1], off[2], off[3], off[4], off[5],
-                           off[6], off[7]);
+                           off[6], off[7], fin.accumulate ? (const char *)d_acc->snt : (const char *)nullptr);
         rc = check_launch(ctx, "acc_merge_kernel");
         if (rc) return rc;
         if (fin.packed) {
@@ -1804,8 +1910,9 @@ extern "C" int ampli_error_reduce(ampli_ctx *ctx, const int32_t *d_recs, int64_t
                                   int32_t S, int32_t first_sample, float C, int32_t cov, const ampli_acc_table *d_acc)
 {
     if (!d_acc) return ctx ? fail(ctx, AMPLI_E_INVALID, "error_reduce: d_acc is required") : AMPLI_E_INVALID;
-    FinOut none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, d_acc, none);
+    if (!ctx) return AMPLI_E_INVALID;
+    FinOut none = {};
+    return error_reduce_impl(ctx, dense_cohort(ctx, d_recs, P, E, S, d_dup_off, nullptr), P, first_sample, C, cov, d_acc, none);
 }
 
 extern "C" int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
@@ -1815,8 +1922,24 @@ extern "C" int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64
 {
     if (!ctx) return AMPLI_E_INVALID;
     if (!d_rate || !d_code) return fail(ctx, AMPLI_E_INVALID, "error_estimate: rate and code outputs are required");
-    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
-    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, 0, C, cov, d_acc, fo);
+    FinOut fo = {};
+    fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
+    return error_reduce_impl(ctx, dense_cohort(ctx, d_recs, P, E, S, d_dup_off, nullptr), P, 0, C, cov, d_acc, fo);
+}
+
+extern "C" int ampli_error_reduce_records(ampli_ctx *ctx, const ampli_records *recs, int64_t P, int32_t first_sample, float C, int32_t cov,
+                                          const ampli_acc_table *d_acc, int32_t accumulate, float *d_rate, uint8_t *d_code, float *d_thr,
+                                          float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    DevCohort co;
+    int rc = cohort_from_records(ctx, recs, P, co);
+    if (rc) return rc;
+    if ((d_rate != nullptr) != (d_code != nullptr)) return fail(ctx, AMPLI_E_INVALID, "error_reduce_records: rate and code come together");
+    FinOut fo = {};
+    fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
+    fo.accumulate = accumulate ? 1 : 0;
+    return error_reduce_impl(ctx, co, P, first_sample, C, cov, d_acc, fo);
 }
 
 extern "C" int ampli_error_reduce_packed(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
@@ -1825,8 +1948,9 @@ extern "C" int ampli_error_reduce_packed(ampli_ctx *ctx, const int32_t *d_recs, 
 {
     if (!ctx) return AMPLI_E_INVALID;
     if (!d_acc || !d_packed) return fail(ctx, AMPLI_E_INVALID, "error_reduce_packed: table and packed buffer are required");
-    FinOut fo = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_packed};
-    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, d_acc, fo);
+    FinOut fo = {};
+    fo.packed = d_packed;
+    return error_reduce_impl(ctx, dense_cohort(ctx, d_recs, P, E, S, d_dup_off, nullptr), P, first_sample, C, cov, d_acc, fo);
 }
 
 extern "C" int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const double *d_packed, const void *d_gm_regions,
@@ -1839,7 +1963,8 @@ extern "C" int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const doub
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     size_t off[9];
     acc_offsets(P, off);
-    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
+    FinOut fo = {};
+    fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
     hipLaunchKernelGGL(error_finalize_merged_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_packed,
                        (const char *)d_gm_regions, off[5] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, (long long)P, C,
                        (int)cov, fo);
@@ -1874,7 +1999,7 @@ extern "C" int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, 
     fo.sl_group = ctx->grp_size; // buffers [n_slices][group][planes][L]; this call fills batch grp_index
     fo.sl_sums = d_sums + (size_t)ctx->grp_index * 21 * (size_t)fo.slice_len;
     fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
-    return error_reduce_impl(ctx, d_recs, P, E, d_dup_off, S, first_sample, C, cov, nullptr, fo);
+    return error_reduce_impl(ctx, dense_cohort(ctx, d_recs, P, E, S, d_dup_off, nullptr), P, first_sample, C, cov, nullptr, fo);
 }
 
 extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_slices, int32_t slice_index,
@@ -1899,7 +2024,8 @@ extern "C" int ampli_error_table_unslice(ampli_ctx *ctx, int64_t P, int32_t n_sl
     if (!ctx) return AMPLI_E_INVALID;
     if (P <= 0 || n_slices < 1 || !d_blocks || !d_rate || !d_code) return fail(ctx, AMPLI_E_INVALID, "error_table_unslice: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
+    FinOut fo = {};
+    fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
     const long long L = ampli_slice_len(P, n_slices);
     hipLaunchKernelGGL(error_table_unslice_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const char *)d_blocks + (size_t)ctx->grp_index * slice_block_bytes(L), (size_t)ctx->grp_size * slice_block_bytes(L),
@@ -1983,25 +2109,31 @@ extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc
     if (!d_acc || d_acc->P <= 0 || !d_rate || !d_code || cov < 1) return fail(ctx, AMPLI_E_INVALID, "error_finalize: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long P = d_acc->P;
-    FinOut fo = {d_rate, d_code, d_thr, d_germ_val, d_germ_present, d_flags, nullptr};
+    FinOut fo = {};
+    fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
     return launch_finalize(ctx, to_ptrs(d_acc), P, C, (int)cov, fo);
 }
 
-static int poisson_call_impl(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
-                             int32_t T, const float *d_thr, const long long thr_L, const size_t thr_bb, const uint8_t *d_ref_code,
-                             int32_t cov, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, const float *d_thr, const long long thr_L, const size_t thr_bb,
+                             const uint8_t *d_ref_code, int32_t cov, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
                              unsigned long long *d_n_calls, double *d_q, float *d_af)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (!d_trecs || P <= 0 || E < 0 || T <= 0 || !d_thr || !d_ref_code || !d_call_mask || cov < 1)
+    const int64_t E = co.E;
+    const int32_t T = co.n;
+    const uint32_t *d_ext_pos = co.ext_pos;
+    if (!co.rv.base || P <= 0 || E < 0 || T <= 0 || !d_thr || !d_ref_code || !d_call_mask || cov < 1)
         return fail(ctx, AMPLI_E_INVALID, "poisson_call: bad argument");
     if (E > 0 && !d_ext_pos) return fail(ctx, AMPLI_E_INVALID, "poisson_call: E > 0 needs ext_pos");
     if (mode != AMPLI_POISSON_FULL && mode != AMPLI_POISSON_PREFILTER) return fail(ctx, AMPLI_E_INVALID, "poisson_call: bad mode");
     if (d_q && mode != AMPLI_POISSON_FULL) return fail(ctx, AMPLI_E_INVALID, "poisson_call: dense q needs AMPLI_POISSON_FULL");
     if (d_calls && (!d_n_calls || capacity < AMPLI_CALL_SHARDS)) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call list needs n_calls and capacity >= AMPLI_CALL_SHARDS");
     if (d_n_calls && !d_calls) capacity = 0;
-    if (((uintptr_t)d_trecs & (ctx->rec_layout == AMPLI_RECORDS_U24 ? 7 : 15)) != 0)
-        return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
+    {
+        const uintptr_t am = co.layout == AMPLI_RECORDS_U24 ? 7 : 15;
+        if (((uintptr_t)co.rv.base & am) != 0 || (E > 0 && ((uintptr_t)co.rv.ext & am) != 0))
+            return fail(ctx, AMPLI_E_INVALID, "poisson_call: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
+    }
     if (P + E >= (1ll << 30)) return fail(ctx, AMPLI_E_RANGE, "poisson_call: P + E must be below 2^30 records per sample");
     if ((T + PC_SAMPLES - 1) / PC_SAMPLES > 65535) return fail(ctx, AMPLI_E_RANGE, "poisson_call: more than 262140 tumour samples in one call (grid limit); split the cohort");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -2011,36 +2143,32 @@ static int poisson_call_impl(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, 
     if (d_n_calls && (mode == AMPLI_POISSON_FULL || d_af)) // the two-kernel path resets the counters in-kernel
         HIP_TRY(ctx, hipMemsetAsync(d_n_calls, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
 #define AMPLI_LAUNCH_PC(MODEV, UV)                                                                                              \
-    hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,  \
+    hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                  \
                        (long long)E, d_ext_pos, (int)T, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, d_call_mask, d_calls,       \
                        (long long)capacity,                                                                                     \
                        d_n_calls, d_q, d_af)
     if (mode == AMPLI_POISSON_FULL) {
-        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U24);
-        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U16);
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U24);
+        else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U16);
         else AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_I32);
     } else if (d_af) { // dense VAFs are a validation output: literal per-lane kernel
-        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U24);
-        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U16);
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U24);
+        else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U16);
         else AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_I32);
     } else {
-        // tumour rows per workgroup: short workgroups win (measured on config 3: 4-6 rows 0.091 ms, 20 rows 0.098 ms,
-        // 96 rows 0.167 ms -- many small workgroups keep every CU fed through the tail); thresholds are re-read per
-        // workgroup from L2.  Only very large panels get longer workgroups, to bound the grid.
-        const long long tiles = (R + 255) / 256;
-        const long long resident = (long long)ctx->n_cu * 8; // 256-thread workgroups at <= 64 VGPRs
-        int rows = T >= 4 ? 4 : T;
-        while (rows < T && tiles * ((T + rows - 1) / rows) > 16 * resident) rows *= 2;
-        if (rows > T) rows = T;
-        long long gy;
-        if (const char *e = getenv("AMPLI_EXP_ROWS")) rows = std::max(1, atoi(e)); // experiment knob
-        gy = (T + rows - 1) / rows;
-        while (gy > 65535) { rows *= 2; gy = (T + rows - 1) / rows; } // gridDim.y limit
+        // one wave per (64-record tile, rows_per_wave tumour rows), four row groups per workgroup.  Few rows per wave =
+        // many short waves that keep every CU fed through the tail; the thresholds of a tile are shared through the
+        // XCD's L2 by the mapping of poisson_stream_kernel, so short waves no longer cost re-reads over the fabric.
+        const long long tiles = (R + 63) / 64, tiles8 = (tiles + 7) / 8 * 8;
+        int rpw = ctx->pc_rows_per_wave > 0 ? ctx->pc_rows_per_wave : 4;
+        if (rpw > T) rpw = T;
+        long long gy = (T + 4 * rpw - 1) / (4 * rpw);
+        while (tiles8 * gy > 0x7fffffffll) { rpw *= 2; gy = (T + 4 * rpw - 1) / (4 * rpw); } // gridDim.x limit
         // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),
         // or what ampli_set_queue_items asked for plus one workgroup's worth of slack per shard (workgroups are dealt
         // to the shards round-robin, so a shard holds at most ceil(blocks/SHARDS) workgroups' items)
         size_t want = (size_t)std::max<long long>(1 << 16, (long long)T * R / 4);
-        const size_t slack = (size_t)AMPLI_CALL_SHARDS * 256 * 3 * (size_t)rows;
+        const size_t slack = (size_t)AMPLI_CALL_SHARDS * 256 * 3 * (size_t)rpw;
         if (ctx->queue_min_items) want = std::max(want, ctx->queue_min_items + slack);
         want = (want + AMPLI_CALL_SHARDS - 1) / AMPLI_CALL_SHARDS * AMPLI_CALL_SHARDS;
         const bool capturing = is_capturing(ctx);
@@ -2067,26 +2195,29 @@ static int poisson_call_impl(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, 
             HIP_TRY(ctx, hipMemsetAsync(qn, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
         else
             ctx->queue_parity ^= 1;
-        dim3 qgrid((unsigned)tiles, (unsigned)gy);
+        dim3 qgrid((unsigned)(tiles8 * gy));
 #define AMPLI_LAUNCH_STREAM(LV)                                                                                                  \
-    hipLaunchKernelGGL(poisson_stream_kernel<LV>, qgrid, dim3(256), 0, ctx->stream, (const int4 *)d_trecs, (long long)P,          \
-                       (long long)E, d_ext_pos, (int)T, rows, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, (PcItem *)ctx->queue,   \
-                       per, qn,                                                                                                   \
-                       (unsigned *)d_call_mask, ctx->d_flags, d_n_calls)
-        if (ctx->rec_layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
-        else if (ctx->rec_layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
+    hipLaunchKernelGGL(poisson_stream_kernel<LV>, qgrid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                          \
+                       (long long)E, d_ext_pos, (int)T, rpw, (unsigned)gy, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, \
+                       (PcItem *)ctx->queue, per, qn, d_call_mask, ctx->d_flags, d_n_calls)
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
+        else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
         else AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_I32);
 #undef AMPLI_LAUNCH_STREAM
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;
         hipStream_t dstream = ctx->stream;
-        if (ctx->async_drain) { // the drain is one scorer-chain latency long: let it run beside whatever the caller enqueues next
+        if (ctx->async_drain) { // let the drain run beside whatever the caller enqueues next
             HIP_TRY(ctx, hipEventRecord(ctx->ev_stream_done, ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_stream_done, 0));
             dstream = ctx->side;
         }
-        hipLaunchKernelGGL(poisson_drain_kernel, dim3((unsigned)(ctx->n_cu * 2)), dim3(256), 0, dstream, (const PcItem *)ctx->queue,
-                           per, qn, (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
+        // AMPLI_CALL_SHARDS x dgy workgroups, 128 items per workgroup pass: one pass while up to ~1.4 % of the records are
+        // queued (0.2 % on the synthetic and Toy_data panels); a workgroup without items leaves after one load
+        const unsigned dgy = (unsigned)(ctx->pc_drain_blocks > 0 ? ctx->pc_drain_blocks
+                                                                 : std::min<long long>(1024, std::max<long long>(16, (long long)T * R / 300000)));
+        hipLaunchKernelGGL(poisson_drain_kernel, dim3(AMPLI_CALL_SHARDS, dgy), dim3(256), 0, dstream, (const PcItem *)ctx->queue, per, qn,
+                           (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
         if (ctx->async_drain) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_drain_done, ctx->side));
             ctx->drain_pending = true;
@@ -2101,8 +2232,20 @@ extern "C" int ampli_poisson_call(ampli_ctx *ctx, const int32_t *d_trecs, int64_
                                   uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
                                   unsigned long long *d_n_calls, double *d_q, float *d_af)
 {
-    return poisson_call_impl(ctx, d_trecs, P, E, d_ext_pos, T, d_thr, 0, 0, d_ref_code, cov, mode, d_call_mask, d_calls, capacity,
-                             d_n_calls, d_q, d_af);
+    if (!ctx) return AMPLI_E_INVALID;
+    return poisson_call_impl(ctx, dense_cohort(ctx, d_trecs, P, E, T, nullptr, d_ext_pos), P, d_thr, 0, 0, d_ref_code, cov, mode, d_call_mask,
+                             d_calls, capacity, d_n_calls, d_q, d_af);
+}
+
+extern "C" int ampli_poisson_call_records(ampli_ctx *ctx, const ampli_records *trecs, int64_t P, const float *d_thr, const uint8_t *d_ref_code,
+                                          int32_t cov, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
+                                          unsigned long long *d_n_calls, double *d_q, float *d_af)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    DevCohort co;
+    int rc = cohort_from_records(ctx, trecs, P, co);
+    if (rc) return rc;
+    return poisson_call_impl(ctx, co, P, d_thr, 0, 0, d_ref_code, cov, mode, d_call_mask, d_calls, capacity, d_n_calls, d_q, d_af);
 }
 
 extern "C" int ampli_poisson_call_blocks(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P, int64_t E, const uint32_t *d_ext_pos,
@@ -2114,8 +2257,8 @@ extern "C" int ampli_poisson_call_blocks(ampli_ctx *ctx, const int32_t *d_trecs,
     if (n_slices < 1 || P <= 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call_blocks: bad argument");
     const long long L = ampli_slice_len(P, n_slices);
     d_blocks = (const char *)d_blocks + (size_t)ctx->grp_index * slice_block_bytes(L); // [n_slices][group][block]: this batch's blocks
-    return poisson_call_impl(ctx, d_trecs, P, E, d_ext_pos, T, (const float *)d_blocks, L, (size_t)ctx->grp_size * slice_block_bytes(L), d_ref_code, cov, mode,
-                             d_call_mask, d_calls, capacity, d_n_calls, d_q, d_af);
+    return poisson_call_impl(ctx, dense_cohort(ctx, d_trecs, P, E, T, nullptr, d_ext_pos), P, (const float *)d_blocks, L,
+                             (size_t)ctx->grp_size * slice_block_bytes(L), d_ref_code, cov, mode, d_call_mask, d_calls, capacity, d_n_calls, d_q, d_af);
 }
 
 extern "C" int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err, int64_t n,

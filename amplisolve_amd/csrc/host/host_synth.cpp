@@ -29,6 +29,16 @@ extern "C" void ampli_host_text_roundtrip_batch(const float *in, int64_t n, floa
 extern "C" int32_t ampli_host_af_limit(int32_t d) { return ampli_af_limit(d); }
 extern "C" int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err) { return ampli_prefilter_nocall(k, rd, err); }
 extern "C" int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err) { return ampli_prefilter_skip_f32(k, rd, ampli_effective_err(err)); }
+// the drain kernel's scorer for one strand of a queued item (k > m = rd*err > 0): Q of p = 1 - (1 - P_series_nodiv(k, m))
+extern "C" void ampli_host_drain_score_batch(const int32_t *k, const int32_t *rd, const float *err, int64_t n, double *q, double *p)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const double m = (double)rd[i] * err[i];
+        const double pv = 1 - (1. - ampli_kf_gammap_series_nodiv((double)k[i], m));
+        if (p) p[i] = pv;
+        if (q) q[i] = ampli_q_from_p(pv);
+    }
+}
 extern "C" void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = ampli_af_limit(d[i]);

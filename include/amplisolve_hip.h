@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define AMPLI_ABI_VERSION 1
+#define AMPLI_ABI_VERSION 2
 #define AMPLI_ABSENT INT32_MIN
 /* record layouts, same field order in all of them:
  *   AMPLI_RECORDS_I32  int32 recs[n_samples][R][8], 32 B per record, absent: recs[..][0] == INT32_MIN
@@ -164,6 +164,42 @@ int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64
                          uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
 
 /*
+ * A cohort on the device described explicitly -- what the streaming command lines use: a cohort is uploaded in
+ * CHUNKS of consecutive samples (visit order) while the next chunk is still being parsed, each chunk in its own
+ * buffers and, if need be, its own layout (24-byte records unless a count of the chunk needs int32).
+ *   recs        DEVICE, primary records [n_samples][row_stride] in `layout`
+ *   row_stride  records between the same position of consecutive samples; 0 = dense (P when `ext` is given, else
+ *               P + E).  A padded stride keeps panels whose row is a large power of two off the same HBM channels.
+ *   ext         DEVICE, extra-occurrence records [n_samples][ext_stride]; NULL = they follow the primaries inside
+ *               each row (the dense interchange layout: recs + P records)
+ *   ext_stride  0 = E
+ *   E, dup_off [P+1] (error_reduce), ext_pos [E] (poisson_call): as in the classic entry points; a chunk may carry
+ *               its own E / dup_off / ext_pos (slots for the multiplicities seen in ITS files)
+ */
+typedef struct ampli_records {
+    const void *recs;
+    int64_t row_stride;
+    const void *ext;
+    int64_t ext_stride;
+    int64_t E;
+    const uint32_t *dup_off;
+    const uint32_t *ext_pos;
+    int32_t layout;
+    int32_t n_samples;
+} ampli_records;
+
+/*
+ * error_reduce over one chunk (EE:1149-1296, EE:1565-1631 as ampli_error_reduce).  accumulate == 0: d_acc is
+ * overwritten (first chunk); accumulate != 0: d_acc holds the state of the EARLIER samples and receives
+ * d_acc (+) chunk -- sums add, the Germ_Max triple composes in sample order, so any chunking of the visit order
+ * gives the table of the single pass.  With d_rate / d_code non-NULL the merged state is finalised in the same
+ * launch (last chunk; outputs as ampli_error_finalize).  Fully asynchronous on the context's stream.
+ */
+int ampli_error_reduce_records(ampli_ctx *ctx, const ampli_records *recs, int64_t P, int32_t first_sample, float C,
+                               int32_t coverage_cutoff, const ampli_acc_table *d_acc, int32_t accumulate, float *d_rate,
+                               uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
+
+/*
  * acc_merge -- ordered combine of nparts partial tables (parts[0] = earliest
  * samples) into d_dst (may alias parts[0]).  Sums add; the germ-max triple
  * composes as the reference's sequential state machine would.  This is the
@@ -248,15 +284,19 @@ int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc, float C,
                          int32_t coverage_cutoff, float *d_rate, uint8_t *d_code, float *d_thr,
                          float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
 
-/* one emitted call (VC:898 true) */
+/* one emitted call (VC:898 true): everything the post-call annotation needs of the record, so that the host does
+ * not have to keep the record array once it is uploaded */
 typedef struct ampli_call {
     int32_t sample;   /* index into the T axis of this launch */
     int32_t record;   /* r in [0, R) */
     int32_t alt;      /* 0..3 = A,C,G,T */
-    int32_t pad;
+    int32_t rd;       /* the RD column of the line (== fw + bw unless the line was irregular, VC:762-765) */
     double q_fw, q_bw;            /* VC:895-896 */
-    float af, af_fw, af_bw, pad2; /* VC:772-817: the reported VAFs */
-} ampli_call;
+    float af, af_fw, af_bw;       /* VC:772-817: the reported VAFs */
+    int32_t k_fw, k_bw;           /* alt reads per strand (Xfw = X - Xrs, Xrs) */
+    int32_t fw, bw;               /* strand depths: sums of the four forward / reverse counts (VC:760-761) */
+    int32_t pad;
+} ampli_call; /* 64 bytes */
 
 #define AMPLI_CALL_SHARDS 32
 #define AMPLI_CALL_COUNTER_STRIDE 16 /* uint64 words between shard counters: one 128-byte line each */
@@ -293,6 +333,11 @@ int ampli_poisson_call_blocks(ampli_ctx *ctx, const int32_t *d_trecs, int64_t P,
                               int32_t T, const void *d_blocks, int32_t n_slices, const uint8_t *d_ref_code,
                               int32_t coverage_cutoff, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls,
                               int64_t capacity, unsigned long long *d_n_calls, double *d_q, float *d_af);
+
+/* poisson_call over an explicitly described cohort / chunk (ampli_records above); d_call_mask is [n_samples][P + E] */
+int ampli_poisson_call_records(ampli_ctx *ctx, const ampli_records *trecs, int64_t P, const float *d_thr,
+                               const uint8_t *d_ref_code, int32_t coverage_cutoff, int32_t mode, uint8_t *d_call_mask,
+                               ampli_call *d_calls, int64_t capacity, unsigned long long *d_n_calls, double *d_q, float *d_af);
 
 /* Asynchronous drain (opt-in).  In prefilter mode poisson_call is two kernels; the second (the dense drain of the
  * queued survivors) is one fp64 scorer chain long and independent of what the caller enqueues next.  With
@@ -331,7 +376,12 @@ int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t see
  * force the number of lane groups per wave (1, 2 or 4; 0 = automatic). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general);
 
-/* Minimum capacity (items of 32 B) of the prefilter queue of ampli_poisson_call; default T*R/4, at least 65536. */
+/* poisson_call (prefilter mode) launch shape; 0 = default for each.  rows_per_wave: tumour rows one wave streams
+ * (a workgroup = 4 waves over one 64-record tile and 4 * rows_per_wave rows).  drain_blocks_per_shard: workgroups per
+ * queue shard in the drain launch.  Results do not depend on either. */
+int ampli_set_poisson_tuning(ampli_ctx *ctx, int32_t rows_per_wave, int32_t drain_blocks_per_shard);
+
+/* Minimum capacity (items of 40 B) of the prefilter queue of ampli_poisson_call; default T*R/4, at least 65536. */
 int ampli_set_queue_items(ampli_ctx *ctx, int64_t items);
 
 /* Flags raised by kernels of this context since the last clear (synchronises the stream). */

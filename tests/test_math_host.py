@@ -119,3 +119,40 @@ def test_af_gate_integer_bound_exhaustive_over_all_depths():
     O.oracle_af_gate_batch(lim1.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), C.c_int64(d.size), out.ctypes.data_as(C.c_void_p))
     assert not out.any()
     assert (np.abs(lim - 0.05 * d.astype(np.float64)) <= 1).all()
+
+
+def test_division_free_series_of_the_drain_kernel_is_the_reference_series():
+    """The drain kernel scores queued items (k > m) with the series of VC:3785-3794 rewritten without divisions and
+    without the early exit.  Against the oracle's literal scorer: p within 1e-9 relative everywhere (the contract is
+    1e-6), the Q = 100 / Q >= 5 / Q >= 20 decisions identical on every point -- including z so close to s that the
+    reference's 99-term cap truncates the series, and depths up to the int32 range."""
+    H = host_lib()
+    rng = np.random.default_rng(8)
+    ks, rds, es = [], [], []
+    for err in (0.0001, 0.0005, 0.002, 0.002189, 0.0035, 0.01, 0.02, 0.05, 0.25):
+        for scale in (50, 300, 1000, 2500, 25000, 400000, 3_000_000, 16_000_000, 500_000_000):
+            rd = rng.integers(max(1, scale // 2), scale * 2, 600)
+            m = rd * float(np.float32(err))
+            # k from just above m (slow convergence, cap region) to far above it (Q = 100)
+            for f in (1.0, 1.01, 1.1, 1.5, 3.0, 10.0):
+                k = np.maximum(np.floor(m * f).astype(np.int64) + rng.integers(1, 4, rd.size), 1)
+                ok = k < (1 << 31) - 1
+                ks.append(k[ok]); rds.append(rd[ok]); es.append(np.full(ok.sum(), err))
+    k = np.concatenate(ks).astype(np.int32)
+    rd = np.concatenate(rds).astype(np.int32)
+    e = np.concatenate(es).astype(np.float32)
+    keep = k.astype(np.float64) > rd.astype(np.float64) * e.astype(np.float64)
+    k, rd, e = k[keep], rd[keep], e[keep]
+    q = np.empty(k.size, np.float64)
+    p = np.empty(k.size, np.float64)
+    H.ampli_host_drain_score_batch(k.ctypes.data_as(C.c_void_p), rd.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), k.size,
+                                   q.ctypes.data_as(C.c_void_p), p.ctypes.data_as(C.c_void_p))
+    qo, po = orc.score_batch(k, rd, e)
+    assert k.size > 200_000
+    # p = 1 - (1 - P) is a multiple of 2^-53: a last-bit difference in P can move it by one such step
+    excess = np.abs(p - po) - (1e-12 * po + 2.3e-16)
+    assert np.max(excess) <= 0, (np.argmax(excess), np.max(excess))
+    for thr in (5.0, 20.0, 100.0):
+        assert np.array_equal(q >= thr, qo >= thr), thr
+    fin = qo < 100
+    assert np.max(np.abs(q[fin] - qo[fin])) < 1e-7
