@@ -58,6 +58,7 @@ HIP_SYMBOLS = {
     "ampli_event_create": (C.c_int, [C.POINTER(vp)]),
     "ampli_event_destroy": (C.c_int, [vp]),
     "ampli_event_record": (C.c_int, [vp, vp]),
+    "ampli_event_sync": (C.c_int, [vp]),
     "ampli_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "ampli_acc_bytes": (sz, [i64]),
     "ampli_acc_bind": (C.c_int, [vp, i64, C.POINTER(AccTable)]),
@@ -72,6 +73,7 @@ HIP_SYMBOLS = {
     "ampli_slice_len": (i64, [i64, i32]),
     "ampli_slice_bytes": (C.c_int, [i64, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "ampli_error_reduce_sliced": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, i32, vp, vp]),
+    "ampli_acc_to_slices": (C.c_int, [vp, C.POINTER(AccTable), i32, vp, vp]),
     "ampli_error_finalize_slice": (C.c_int, [vp, i64, i32, i32, vp, vp, f32, i32, vp]),
     "ampli_error_table_unslice": (C.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]),
     "ampli_acc_merge": (C.c_int, [vp, C.POINTER(AccTable), C.POINTER(AccTable), i32]),
@@ -111,6 +113,8 @@ class HostShard(C.Structure):
                 ("ee_gather", HOOK), ("or_flags", OR_FLAGS), ("rows_before", ROWS_BEFORE), ("barrier", HOOK)]
 
 
+CHUNK_FN = C.CFUNCTYPE(C.c_int, vp, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64)
+
 HOST_SYMBOLS = {
     "ampli_host_synth_fill": (C.c_int, [vp, i64, i32, i32, u64, i32, i32]),
     "ampli_host_synth_ref": (C.c_int, [vp, i64, u64]),
@@ -140,6 +144,7 @@ HOST_SYMBOLS = {
     "ampli_host_cohort_stats": (None, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]),
     "ampli_host_position": (C.c_int, [vp, i64, C.c_char_p, C.c_int, C.POINTER(i32)]),
     "ampli_host_sample_order": (C.c_int, [C.c_char_p, C.c_char_p, i64]),
+    "ampli_host_stream_chunks": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, i64, CHUNK_FN, vp]),
     "ampli_host_write_error_table": (C.c_int, [vp, vp, vp, vp, vp, C.c_char_p]),
     "ampli_host_read_error_table": (C.c_int, [C.c_char_p, C.POINTER(vp), vp, i64]),
     "ampli_host_run_error_estimation": (C.c_int, [C.c_char_p] * 8),

@@ -282,6 +282,7 @@ extern "C" int ampli_event_record(ampli_ctx *ctx, void *ev)
     HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
     return AMPLI_OK;
 }
+extern "C" int ampli_event_sync(void *ev) { return hipEventSynchronize((hipEvent_t)ev) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP; }
 extern "C" int ampli_event_elapsed_ms(void *a, void *b, float *ms)
 {
     if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return AMPLI_E_HIP;
@@ -2000,6 +2001,21 @@ extern "C" int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, 
     fo.sl_sums = d_sums + (size_t)ctx->grp_index * 21 * (size_t)fo.slice_len;
     fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
     return error_reduce_impl(ctx, dense_cohort(ctx, d_recs, P, E, S, d_dup_off, nullptr), P, first_sample, C, cov, nullptr, fo);
+}
+
+extern "C" int ampli_acc_to_slices(ampli_ctx *ctx, const ampli_acc_table *d_acc, int32_t n_slices, double *d_sums, float *d_gm)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_acc || !acc_is_bound(d_acc) || n_slices < 1 || !d_sums || !d_gm) return fail(ctx, AMPLI_E_INVALID, "acc_to_slices: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const long long P = d_acc->P;
+    FinOut fo = {};
+    fo.slice_len = ampli_slice_len(P, n_slices);
+    fo.sl_group = ctx->grp_size;
+    fo.sl_sums = d_sums + (size_t)ctx->grp_index * 21 * (size_t)fo.slice_len;
+    fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
+    hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, fo);
+    return check_launch(ctx, "acc_pack_sliced_kernel");
 }
 
 extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_slices, int32_t slice_index,

@@ -1,4 +1,5 @@
-// amplisolve_amd/csrc/host/aseq.cpp -- .PILEUP.ASEQ ingest: file list, visit order, parallel parse, SoA pack.
+// amplisolve_amd/csrc/host/aseq.cpp -- .PILEUP.ASEQ ingest: file list, visit order, parallel parse straight into the
+// device record layout, chunked hand-over to the pipelines (replaces the parse loops EE:1100-1149 and VC:699-752).
 #include <fcntl.h>
 #include <glob.h>
 #include <sys/mman.h>
@@ -7,11 +8,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -68,6 +72,56 @@ std::vector<std::pair<std::string, std::string>> list_count_files(const std::str
     return out;
 }
 
+std::vector<std::pair<std::string, std::string>> shard_of_files(const std::vector<std::pair<std::string, std::string>> &files, int shard_index,
+                                                                int shard_count, int *first)
+{
+    // contiguous range of the visit order; earlier shards take the remainder (dist.py::shard_range)
+    const int n = (int)files.size(), base = n / shard_count, rem = n % shard_count;
+    const int lo = shard_index * base + std::min(shard_index, rem), hi = lo + base + (shard_index < rem ? 1 : 0);
+    if (first) *first = lo;
+    return std::vector<std::pair<std::string, std::string>>(files.begin() + lo, files.begin() + hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// record layouts on the host: the packer writes what the kernels read (include/amplisolve_hip.h)
+// ---------------------------------------------------------------------------------------------------------
+size_t record_bytes(int layout) { return layout == AMPLI_RECORDS_U24 ? 24 : (layout == AMPLI_RECORDS_U16 ? 16 : 32); }
+
+static inline void put_record(int layout, char *dst, const int32_t rec[8])
+{
+    if (layout == AMPLI_RECORDS_U24) {
+        // 8 x 24-bit little-endian fields as three 64-bit words
+        const uint64_t f0 = (uint32_t)rec[0], f1 = (uint32_t)rec[1], f2 = (uint32_t)rec[2], f3 = (uint32_t)rec[3], f4 = (uint32_t)rec[4],
+                       f5 = (uint32_t)rec[5], f6 = (uint32_t)rec[6], f7 = (uint32_t)rec[7];
+        const uint64_t w0 = f0 | (f1 << 24) | (f2 << 48);
+        const uint64_t w1 = (f2 >> 16) | (f3 << 8) | (f4 << 32) | (f5 << 56);
+        const uint64_t w2 = (f5 >> 8) | (f6 << 16) | (f7 << 40);
+        memcpy(dst, &w0, 8); memcpy(dst + 8, &w1, 8); memcpy(dst + 16, &w2, 8);
+    } else if (layout == AMPLI_RECORDS_U16) {
+        uint16_t v[8];
+        for (int j = 0; j < 8; ++j) v[j] = (uint16_t)rec[j];
+        memcpy(dst, v, 16);
+    } else {
+        memcpy(dst, rec, 32);
+    }
+}
+
+void fill_absent(int layout, char *dst, size_t n_records)
+{
+    if (!n_records) return;
+    int32_t rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    rec[0] = layout == AMPLI_RECORDS_U24 ? 0xFFFFFF : (layout == AMPLI_RECORDS_U16 ? 0xFFFF : AMPLI_ABSENT);
+    const size_t rb = record_bytes(layout);
+    put_record(layout, dst, rec);
+    // doubling copy: one pattern record, then memcpy of what is already there
+    size_t done = 1;
+    while (done < n_records) {
+        const size_t k = std::min(done, n_records - done);
+        memcpy(dst + done * rb, dst, k * rb);
+        done += k;
+    }
+}
+
 namespace {
 
 struct Extra {
@@ -77,11 +131,12 @@ struct Extra {
 };
 
 struct FileResult {
-    std::vector<int32_t> main;   // [P][8]
-    std::vector<int32_t> line;   // [P]
     std::vector<Extra> extras;
+    std::vector<Irregular> irregular; // .sample is filled in by the caller; .record holds the POSITION here
     int64_t n_lines = 0, n_off = 0, n_irregular = 0, n_malformed = 0;
+    bool needs_i32 = false; // a count above 2^24 - 2: the chunk has to be packed as int32
     std::string error;
+    int error_code = 0;
 };
 
 inline const char *skip_ws(const char *p, const char *e)
@@ -102,29 +157,40 @@ inline bool parse_int(const char *&p, const char *e, int64_t &v)
     if (*p == '-' || *p == '+') { neg = *p == '-'; ++p; }
     if (p >= e || *p < '0' || *p > '9') return false;
     int64_t x = 0;
-    while (p < e && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; }
+    int digits = 0;
+    while (p < e && *p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); ++p; if (++digits > 17) return false; }
     v = neg ? -x : x;
     return true;
 }
 
 // One file.  Columns: chr pos dbsnp MAF ref alt A C G T RD Ars Crs Grs Trs (EE:1149, VC:752); the first line
-// is the header (EE:1113, VC:721).  fw = X - Xrs (EE:1155-1158).
-void parse_file(const Panel &panel, const std::string &path, bool keep_line, FileResult &out)
+// is the header (EE:1113, VC:721).  fw = X - Xrs (EE:1155-1158).  The first line of a panel position goes straight
+// into dst (this sample's row of P records in `layout`, pre-filled as absent by this function); further lines of the
+// same position (overlapping amplicons) are returned as extras.  line: optional [P] data-line index of the primaries.
+void parse_file(const Panel &panel, const std::string &path, int layout, char *dst, int32_t *line, FileResult &out)
 {
     const int64_t P = panel.P();
-    out.main.assign((size_t)P * 8, 0);
-    for (int64_t p = 0; p < P; ++p) out.main[(size_t)p * 8] = AMPLI_ABSENT;
-    if (keep_line) out.line.assign((size_t)P, -1);
+    const size_t rb = record_bytes(layout);
+    fill_absent(layout, dst, (size_t)P);
+    if (line) std::fill_n(line, (size_t)P, -1);
     std::vector<uint32_t> occ((size_t)P, 0); // occurrences so far of each position in THIS file
+    const int64_t max_count = layout == AMPLI_RECORDS_U24 ? 0xFFFFFE : (layout == AMPLI_RECORDS_U16 ? 65534 : INT32_MAX);
 
     const int fd = open(path.c_str(), O_RDONLY);
-    if (fd < 0) { out.error = "Cannot open " + path; return; }
+    if (fd < 0) { out.error = "Cannot open " + path; out.error_code = AMPLI_E_INVALID; return; }
     struct stat st;
     fstat(fd, &st);
     const size_t len = (size_t)st.st_size;
     const char *base = len ? (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
-    if (len && base == MAP_FAILED) { close(fd); out.error = "mmap failed for " + path; return; }
+    if (len && base == MAP_FAILED) { close(fd); out.error = "mmap failed for " + path; out.error_code = AMPLI_E_INVALID; return; }
+    if (len) madvise((void *)base, len, MADV_SEQUENTIAL);
     const char *cur = base, *end = base + len;
+    auto bail = [&](const std::string &msg) {
+        out.error = msg;
+        out.error_code = AMPLI_E_RANGE;
+        if (base) munmap((void *)base, len);
+        close(fd);
+    };
     // header
     while (cur < end && *cur != '\n') ++cur;
     if (cur < end) ++cur;
@@ -170,15 +236,26 @@ void parse_file(const Panel &panel, const std::string &path, bool keep_line, Fil
                 } else {
                     prev_p = pi;
                     const int64_t A = v[0], C = v[1], G = v[2], T = v[3], RD = v[4];
-                    int32_t rec[8] = {(int32_t)(A - v[5]), (int32_t)(C - v[6]), (int32_t)(G - v[7]), (int32_t)(T - v[8]),
-                                      (int32_t)v[5], (int32_t)v[6], (int32_t)v[7], (int32_t)v[8]};
-                    if (A + C + G + T != RD) { // EE:1178-1181, VC:762-765
-                        ++out.n_irregular;
+                    const int64_t w[8] = {A - v[5], C - v[6], G - v[7], T - v[8], v[5], v[6], v[7], v[8]};
+                    int32_t rec[8];
+                    for (int j = 0; j < 8; ++j) {
+                        // 0 <= Xrs <= X and everything inside int32: anything else is not a read count (AMPLI_E_RANGE, as
+                        // include/amplisolve_hip.h promises of the packer)
+                        if (w[j] < 0 || w[j] > INT32_MAX)
+                            return bail(path + ": data line " + std::to_string(line_idx + 1) +
+                                        ": a strand count is negative (reverse count above the total) or beyond int32");
+                        if (w[j] > max_count) out.needs_i32 = true;
+                        rec[j] = (int32_t)w[j];
                     }
                     const uint32_t k = occ[pi]++;
+                    if (A + C + G + T != RD) { // EE:1178-1181, VC:762-765: such a line is used with its own RD column (EE:1229, VC:895)
+                        ++out.n_irregular;
+                        if (RD < INT32_MIN || RD > INT32_MAX) return bail(path + ": data line " + std::to_string(line_idx + 1) + ": RD beyond int32");
+                        out.irregular.push_back(Irregular{0u, (uint32_t)pi, k, (int32_t)RD});
+                    }
                     if (k == 0) {
-                        memcpy(&out.main[(size_t)pi * 8], rec, sizeof rec);
-                        if (keep_line) out.line[(size_t)pi] = line_idx;
+                        if (!out.needs_i32) put_record(layout, dst + (size_t)pi * rb, rec);
+                        if (line) line[(size_t)pi] = line_idx;
                     } else {
                         Extra e;
                         e.p = (uint32_t)pi; e.k = k; e.line = line_idx;
@@ -195,20 +272,248 @@ void parse_file(const Panel &panel, const std::string &path, bool keep_line, Fil
     close(fd);
 }
 
+void *host_alloc(size_t bytes, bool &pinned)
+{
+    const HipApi *api = hip_api();
+    void *mem = nullptr;
+    if (api && api->device_count() > 0 && api->pinned_alloc(bytes ? bytes : 32, &mem) == AMPLI_OK) { pinned = true; return mem; }
+    pinned = false;
+    return aligned_alloc(256, (bytes + 255) / 256 * 256 + 256);
+}
+
+void host_free(void *p, bool pinned)
+{
+    if (!p) return;
+    const HipApi *api = pinned ? hip_api() : nullptr;
+    if (pinned && api) api->pinned_free(p);
+    else free(p);
+}
+
 } // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// ChunkStream: the cohort as a sequence of chunks of consecutive samples, parsed by a producer thread (+ workers)
+// into a small ring of pinned buffers while the consumer uploads / reduces the previous chunk.
+// ---------------------------------------------------------------------------------------------------------
+Chunk::~Chunk()
+{
+    host_free(prim, prim_pinned);
+    host_free(ext, ext_pinned);
+}
+
+struct ChunkStream::Impl {
+    const Panel &panel;
+    std::vector<std::pair<std::string, std::string>> files;
+    int n_threads = 1;
+    bool keep_line = false;
+    int per_chunk = 1, n_chunks = 0;
+    std::vector<std::unique_ptr<Chunk>> slots;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> free_slots, ready; // ready: slot indices in chunk order
+    bool done = false, stop = false, failed = false;
+    Error err{0, ""};
+    std::thread producer;
+    double parse_seconds = 0;
+
+    explicit Impl(const Panel &p) : panel(p) {}
+
+    void fill(Chunk &c, int ci)
+    {
+        const int64_t P = panel.P();
+        const int lo = ci * per_chunk, hi = std::min((int)files.size(), lo + per_chunk), n = hi - lo;
+        c.index = ci; c.first = lo; c.n = n; c.P = P; c.last = ci == n_chunks - 1;
+        c.n_lines = c.n_offpanel = c.n_irregular = c.n_malformed = 0;
+        c.irregular.clear();
+        int layout = AMPLI_RECORDS_U24;
+        std::vector<FileResult> res;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            res.assign((size_t)n, FileResult());
+            const size_t rb = record_bytes(layout);
+            if (keep_line) c.line_prim.assign((size_t)n * P, -1);
+            std::atomic<int> next{0};
+            auto work = [&] {
+                for (int i; (i = next.fetch_add(1)) < n;)
+                    parse_file(panel, files[(size_t)lo + i].first, layout, (char *)c.prim + (size_t)i * P * rb,
+                               keep_line ? c.line_prim.data() + (size_t)i * P : nullptr, res[(size_t)i]);
+            };
+            const int nt = std::max(1, std::min(n_threads, n));
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; ++t) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+            bool widen = false;
+            for (auto &r : res) {
+                if (!r.error.empty()) throw Error{r.error_code ? r.error_code : AMPLI_E_INVALID, r.error};
+                widen |= r.needs_i32;
+            }
+            if (!widen) break;
+            if (layout == AMPLI_RECORDS_I32) throw Error{AMPLI_E_RANGE, "count beyond int32"};
+            layout = AMPLI_RECORDS_I32; // a count above 2^24 - 2 somewhere in the chunk: pack it again as int32
+        }
+        c.layout = layout;
+        // extras of this chunk: slots for the largest multiplicity any of ITS files shows at a position
+        std::vector<uint32_t> mult((size_t)P, 0);
+        bool any_extra = false;
+        for (auto &r : res)
+            for (auto &e : r.extras) { any_extra = true; if (e.k > mult[e.p]) mult[e.p] = e.k; }
+        c.dup_off.assign((size_t)P + 1, 0);
+        if (any_extra)
+            for (int64_t p = 0; p < P; ++p) c.dup_off[p + 1] = c.dup_off[p] + mult[p];
+        c.E = c.dup_off[P];
+        c.ext_pos.assign((size_t)c.E, 0);
+        for (int64_t p = 0; p < P && any_extra; ++p)
+            for (uint32_t e = c.dup_off[p]; e < c.dup_off[p + 1]; ++e) c.ext_pos[e] = (uint32_t)p;
+        const size_t rb = record_bytes(layout);
+        const size_t need = (size_t)n * (size_t)c.E * rb;
+        if (need > c.ext_cap) {
+            host_free(c.ext, c.ext_pinned);
+            c.ext = nullptr;
+            c.ext_cap = need + need / 2 + 4096;
+            c.ext = host_alloc(c.ext_cap, c.ext_pinned);
+            if (!c.ext) throw Error{AMPLI_E_NOMEM, "cannot allocate the extra-occurrence records"};
+        }
+        if (c.E) fill_absent(layout, (char *)c.ext, (size_t)n * (size_t)c.E);
+        if (keep_line) c.line_ext.assign((size_t)n * c.E, -1);
+        for (int i = 0; i < n; ++i) {
+            FileResult &r = res[(size_t)i];
+            for (auto &e : r.extras) {
+                const size_t slot = (size_t)c.dup_off[e.p] + (e.k - 1);
+                put_record(layout, (char *)c.ext + ((size_t)i * c.E + slot) * rb, e.rec);
+                if (keep_line) c.line_ext[(size_t)i * c.E + slot] = e.line;
+            }
+            for (auto &ir : r.irregular) {
+                Irregular x = ir;
+                x.sample = (uint32_t)i;
+                // record slot of occurrence k of position p inside this chunk's layout
+                x.record = ir.occurrence == 0 ? ir.record : (uint32_t)(P + c.dup_off[ir.record] + (ir.occurrence - 1));
+                c.irregular.push_back(x);
+            }
+            c.n_lines += r.n_lines; c.n_offpanel += r.n_off; c.n_irregular += r.n_irregular; c.n_malformed += r.n_malformed;
+        }
+    }
+
+    void run()
+    {
+        try {
+            for (int ci = 0; ci < n_chunks; ++ci) {
+                int slot;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || !free_slots.empty(); });
+                    if (stop) return;
+                    slot = free_slots.back();
+                    free_slots.pop_back();
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                fill(*slots[(size_t)slot], ci);
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    parse_seconds += dt;
+                    ready.push_back(slot);
+                }
+                cv.notify_all();
+            }
+        } catch (const Error &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            err = e;
+            failed = true;
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(mu);
+            err = Error{AMPLI_E_NOMEM, std::string("ingest: ") + e.what()};
+            failed = true;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            done = true;
+        }
+        cv.notify_all();
+    }
+};
+
+ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, std::string>> files, int n_threads, bool keep_line_no,
+                         size_t chunk_bytes, int n_slots)
+    : im(new Impl(panel))
+{
+    im->files = std::move(files);
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    im->n_threads = std::max(1, n_threads);
+    im->keep_line = keep_line_no;
+    const int64_t P = panel.P();
+    const int S = (int)im->files.size();
+    // samples per chunk: about chunk_bytes of 24-byte records, at least one sample, and not so few that the parser
+    // threads idle
+    int per = (int)std::max<int64_t>(1, (int64_t)(chunk_bytes / (size_t)std::max<int64_t>(1, P * 24)));
+    per = std::max(per, std::min(S, im->n_threads));
+    per = std::min(per, std::max(1, S));
+    im->per_chunk = per;
+    im->n_chunks = S == 0 ? 0 : (S + per - 1) / per;
+    n_slots = std::max(1, std::min(n_slots, std::max(1, im->n_chunks)));
+    for (int i = 0; i < n_slots; ++i) {
+        std::unique_ptr<Chunk> c(new Chunk());
+        c->slot = i;
+        c->prim_cap = (size_t)per * (size_t)P * 32; // room for the int32 layout
+        c->prim = host_alloc(c->prim_cap, c->prim_pinned);
+        if (!c->prim) throw Error{AMPLI_E_NOMEM, "cannot allocate the record buffers"};
+        im->slots.push_back(std::move(c));
+        im->free_slots.push_back(i);
+    }
+    im->producer = std::thread([this] { im->run(); });
+}
+
+ChunkStream::~ChunkStream()
+{
+    {
+        std::lock_guard<std::mutex> lk(im->mu);
+        im->stop = true;
+    }
+    im->cv.notify_all();
+    if (im->producer.joinable()) im->producer.join();
+    delete im;
+}
+
+int ChunkStream::samples_per_chunk() const { return im->per_chunk; }
+int ChunkStream::chunks() const { return im->n_chunks; }
+double ChunkStream::parse_seconds() const
+{
+    std::lock_guard<std::mutex> lk(im->mu);
+    return im->parse_seconds;
+}
+
+Chunk *ChunkStream::next()
+{
+    std::unique_lock<std::mutex> lk(im->mu);
+    im->cv.wait(lk, [&] { return !im->ready.empty() || im->done; });
+    if (im->ready.empty()) {
+        if (im->failed) throw im->err;
+        return nullptr;
+    }
+    const int slot = im->ready.front();
+    im->ready.erase(im->ready.begin());
+    return im->slots[(size_t)slot].get();
+}
+
+void ChunkStream::release(Chunk *c)
+{
+    {
+        std::lock_guard<std::mutex> lk(im->mu);
+        im->free_slots.push_back(c->slot);
+    }
+    im->cv.notify_all();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cohort_load: the whole directory as ONE dense int32 array [S][P+E][8] (the interchange layout the oracle, the tests
+// and the Python harness speak).  The command lines stream chunks instead (ChunkStream above).
+// ---------------------------------------------------------------------------------------------------------
 void cohort_load(const Panel &panel, const std::string &dir, const std::string &list_file, int n_threads, bool keep_line_no,
                  bool print_irregular, Cohort &out, int shard_index, int shard_count)
 {
     auto files = list_count_files(dir, list_file);
     out.total_samples = (int)files.size();
     out.first_sample = 0;
-    if (shard_count > 1) { // contiguous range of the visit order; earlier shards take the remainder (dist.py::shard_range)
-        const int n = (int)files.size(), base = n / shard_count, rem = n % shard_count;
-        const int lo = shard_index * base + std::min(shard_index, rem), hi = lo + base + (shard_index < rem ? 1 : 0);
-        files = decltype(files)(files.begin() + lo, files.begin() + hi);
-        out.first_sample = lo;
-    }
+    if (shard_count > 1) files = shard_of_files(files, shard_index, shard_count, &out.first_sample);
     const int S = (int)files.size();
     const int64_t P = panel.P();
     out.paths.clear(); out.names.clear();
@@ -216,6 +521,7 @@ void cohort_load(const Panel &panel, const std::string &dir, const std::string &
     out.P = P;
 
     std::vector<FileResult> res((size_t)S);
+    std::vector<std::vector<int32_t>> prim((size_t)S), lines((size_t)S);
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
     if (n_threads > S) n_threads = S;
     if (n_threads < 1) n_threads = 1;
@@ -223,11 +529,16 @@ void cohort_load(const Panel &panel, const std::string &dir, const std::string &
     std::vector<std::thread> th;
     for (int t = 0; t < n_threads; ++t)
         th.emplace_back([&] {
-            for (int s; (s = next.fetch_add(1)) < S;) parse_file(panel, out.paths[s], keep_line_no, res[s]);
+            for (int s; (s = next.fetch_add(1)) < S;) {
+                prim[(size_t)s].resize((size_t)P * 8);
+                if (keep_line_no) lines[(size_t)s].resize((size_t)P);
+                parse_file(panel, out.paths[(size_t)s], AMPLI_RECORDS_I32, (char *)prim[(size_t)s].data(),
+                           keep_line_no ? lines[(size_t)s].data() : nullptr, res[(size_t)s]);
+            }
         });
     for (auto &t : th) t.join();
     for (int s = 0; s < S; ++s)
-        if (!res[s].error.empty()) throw Error{AMPLI_E_INVALID, res[s].error};
+        if (!res[s].error.empty()) throw Error{res[s].error_code ? res[s].error_code : AMPLI_E_INVALID, res[s].error};
     if (print_irregular) // the reference's own message, once per offending line (EE:1178-1181, VC:762-765)
         for (int s = 0; s < S; ++s)
             for (int64_t i = 0; i < res[s].n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl;
@@ -246,30 +557,29 @@ void cohort_load(const Panel &panel, const std::string &dir, const std::string &
 
     const int64_t R = P + out.E;
     const size_t bytes = (size_t)S * R * 8 * sizeof(int32_t);
-    const HipApi *api = hip_api();
-    void *mem = nullptr;
-    if (api && api->device_count() > 0 && api->pinned_alloc(bytes ? bytes : 32, &mem) == AMPLI_OK) out.pinned = true;
-    else { mem = aligned_alloc(256, (bytes + 255) / 256 * 256 + 256); out.pinned = false; }
-    if (!mem) throw Error{AMPLI_E_NOMEM, "cannot allocate the record array"};
-    out.recs = (int32_t *)mem;
+    out.recs = (int32_t *)host_alloc(bytes, out.pinned);
+    if (!out.recs) throw Error{AMPLI_E_NOMEM, "cannot allocate the record array"};
     if (keep_line_no) out.line_no.assign((size_t)S * R, -1);
+    out.irregular.clear();
     for (int s = 0; s < S; ++s) {
         int32_t *dst = out.recs + (size_t)s * R * 8;
-        memcpy(dst, res[s].main.data(), (size_t)P * 8 * sizeof(int32_t));
-        for (int64_t e = 0; e < out.E; ++e) {
-            int32_t *x = dst + (size_t)(P + e) * 8;
-            x[0] = AMPLI_ABSENT;
-            for (int j = 1; j < 8; ++j) x[j] = 0;
-        }
-        if (keep_line_no) memcpy(&out.line_no[(size_t)s * R], res[s].line.data(), (size_t)P * sizeof(int32_t));
+        memcpy(dst, prim[(size_t)s].data(), (size_t)P * 8 * sizeof(int32_t));
+        fill_absent(AMPLI_RECORDS_I32, (char *)(dst + (size_t)P * 8), (size_t)out.E);
+        if (keep_line_no) memcpy(&out.line_no[(size_t)s * R], lines[(size_t)s].data(), (size_t)P * sizeof(int32_t));
         for (auto &e : res[s].extras) {
             const size_t slot = (size_t)P + out.dup_off[e.p] + (e.k - 1);
             memcpy(dst + slot * 8, e.rec, sizeof e.rec);
             if (keep_line_no) out.line_no[(size_t)s * R + slot] = e.line;
         }
+        for (auto &ir : res[s].irregular) {
+            Irregular x = ir;
+            x.sample = (uint32_t)s;
+            x.record = ir.occurrence == 0 ? ir.record : (uint32_t)(P + out.dup_off[ir.record] + (ir.occurrence - 1));
+            out.irregular.push_back(x);
+        }
         out.n_lines += res[s].n_lines; out.n_offpanel += res[s].n_off;
         out.n_irregular += res[s].n_irregular; out.n_malformed += res[s].n_malformed;
-        FileResult().main.swap(res[s].main); // release as we go
+        std::vector<int32_t>().swap(prim[(size_t)s]); // release as we go
     }
 }
 

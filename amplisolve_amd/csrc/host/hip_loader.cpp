@@ -53,6 +53,8 @@ static void load()
     BIND(slice_len, "ampli_slice_len") BIND(slice_bytes, "ampli_slice_bytes") BIND(error_reduce_sliced, "ampli_error_reduce_sliced")
     BIND(error_finalize_slice, "ampli_error_finalize_slice") BIND(error_table_unslice, "ampli_error_table_unslice")
     BIND(poisson_call, "ampli_poisson_call") BIND(set_tuning, "ampli_set_tuning") BIND(ctx_flags, "ampli_ctx_flags") BIND(set_queue_items, "ampli_set_queue_items")
+    BIND(error_reduce_records, "ampli_error_reduce_records") BIND(poisson_call_records, "ampli_poisson_call_records") BIND(acc_to_slices, "ampli_acc_to_slices")
+    BIND(event_create, "ampli_event_create") BIND(event_destroy, "ampli_event_destroy") BIND(event_record, "ampli_event_record") BIND(event_sync, "ampli_event_sync")
 #undef BIND
     if (g_api.abi_version() != AMPLI_ABI_VERSION) { g_why = "libamplisolve_hip.so ABI version mismatch"; return; }
     g_ok = true;

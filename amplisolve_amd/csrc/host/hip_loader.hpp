@@ -43,6 +43,16 @@ struct HipApi {
     int (*poisson_call)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, const float *,
                         const uint8_t *, int32_t, int32_t, uint8_t *, ampli_call *, int64_t, unsigned long long *, double *,
                         float *);
+    // streamed cohorts: one launch per uploaded chunk of samples
+    int (*error_reduce_records)(ampli_ctx *, const ampli_records *, int64_t, int32_t, float, int32_t, const ampli_acc_table *, int32_t, float *,
+                                uint8_t *, float *, float *, uint8_t *, int32_t *);
+    int (*poisson_call_records)(ampli_ctx *, const ampli_records *, int64_t, const float *, const uint8_t *, int32_t, int32_t, uint8_t *,
+                                ampli_call *, int64_t, unsigned long long *, double *, float *);
+    int (*acc_to_slices)(ampli_ctx *, const ampli_acc_table *, int32_t, double *, float *);
+    int (*event_create)(void **);
+    int (*event_destroy)(void *);
+    int (*event_record)(ampli_ctx *, void *);
+    int (*event_sync)(void *);
 };
 
 const HipApi *hip_api(std::string *why);

@@ -40,6 +40,16 @@ struct Panel {
     void set_ref(uint32_t p, const std::string &base);
 };
 
+// A line whose RD column differs from A+C+G+T (EE:1178-1181, VC:762-765).  The reference keeps using the column:
+// as the denominator of the Germ_Max AF (EE:1229-1232) and, in the caller, as RD in AF = X/RD and in the forward depth
+// RD - RD_reverse of the Poisson test (VC:814-817, VC:895).  Sparse side list next to the dense records.
+struct Irregular {
+    uint32_t sample;     // sample index inside the cohort / chunk
+    uint32_t record;     // record slot in [0, P+E)
+    uint32_t occurrence; // which line of that position in the file (0 = the primary record)
+    int32_t rd;          // the RD column
+};
+
 // A directory of .PILEUP.ASEQ files packed into the record SoA of include/amplisolve_hip.h
 struct Cohort {
     std::vector<std::string> paths;   // in visit order (EE:1081 / VC:672)
@@ -50,6 +60,7 @@ struct Cohort {
     std::vector<uint32_t> dup_off;    // [P+1]
     std::vector<uint32_t> ext_pos;    // [E]
     std::vector<int32_t> line_no;     // [S][P+E] data-line index inside the sample's file, -1 absent
+    std::vector<Irregular> irregular; // lines with RD != A+C+G+T
     int64_t n_lines = 0, n_offpanel = 0, n_irregular = 0, n_malformed = 0;
     int first_sample = 0, total_samples = 0; // this cohort = samples [first_sample, first_sample + S()) of the directory's visit order
     ~Cohort();
@@ -62,6 +73,52 @@ struct Error {
     std::string msg;
 };
 
+// One upload unit of a streamed cohort: consecutive samples of the visit order, records already in the layout the
+// kernels read (24-byte records; int32 when a count of the chunk needs it), extras in their own array with the
+// chunk's own slot layout (ampli_records of include/amplisolve_hip.h describes exactly this).
+struct Chunk {
+    int slot = 0, index = 0;       // ring slot; chunk number
+    int first = 0, n = 0;          // samples [first, first + n) of the stream's file list
+    bool last = false;
+    int layout = AMPLI_RECORDS_U24;
+    int64_t P = 0, E = 0;
+    void *prim = nullptr;          // [n][P] records, pinned when a GPU is present
+    size_t prim_cap = 0;
+    bool prim_pinned = false;
+    void *ext = nullptr;           // [n][E] records
+    size_t ext_cap = 0;
+    bool ext_pinned = false;
+    std::vector<uint32_t> dup_off; // [P+1]
+    std::vector<uint32_t> ext_pos; // [E]
+    std::vector<int32_t> line_prim, line_ext; // [n][P], [n][E] data-line index inside the sample's file (-1 absent); variant calling only
+    std::vector<Irregular> irregular;
+    int64_t n_lines = 0, n_offpanel = 0, n_irregular = 0, n_malformed = 0;
+    Chunk() = default;
+    Chunk(const Chunk &) = delete;
+    Chunk &operator=(const Chunk &) = delete;
+    ~Chunk();
+};
+
+// The cohort as a stream of chunks: a producer thread (with n_threads parser workers) fills a small ring of pinned
+// buffers ahead of the consumer, so parsing of chunk k+1 overlaps the upload and the kernels of chunk k and the host
+// never holds more than n_slots chunks (replaces the parse loops of EE:1100-1149 / VC:699-752).
+class ChunkStream {
+public:
+    ChunkStream(const Panel &panel, std::vector<std::pair<std::string, std::string>> files, int n_threads, bool keep_line_no,
+                size_t chunk_bytes, int n_slots);
+    ~ChunkStream();
+    ChunkStream(const ChunkStream &) = delete;
+    ChunkStream &operator=(const ChunkStream &) = delete;
+    Chunk *next();            // next chunk in order, nullptr after the last; rethrows the producer's Error
+    void release(Chunk *c);   // the chunk's buffers may be refilled
+    int samples_per_chunk() const;
+    int chunks() const;
+    double parse_seconds() const; // producer time spent parsing so far
+private:
+    struct Impl;
+    Impl *im;
+};
+
 // ---- panel.cpp ----
 void panel_from_bed(const std::string &bed_path, Panel &out);                   // throws Error
 void panel_load_refbases_file(Panel &p, const std::string &path);               // chrom pos base per line (EE:963)
@@ -69,6 +126,10 @@ void panel_load_fasta(Panel &p, const std::string &fasta_path);                 
 void panel_write_interm_files(const Panel &p, const std::string &dir, int seed);// EE:601, 657-664
 // ---- aseq.cpp ----
 std::vector<std::pair<std::string, std::string>> list_count_files(const std::string &dir, const std::string &list_file); // EE:552-559, 794-841
+std::vector<std::pair<std::string, std::string>> shard_of_files(const std::vector<std::pair<std::string, std::string>> &files, int shard_index,
+                                                                int shard_count, int *first);
+size_t record_bytes(int layout);
+void fill_absent(int layout, char *dst, size_t n_records);
 // shard_index / shard_count: keep only that contiguous range of the visit order (multi-process runs)
 void cohort_load(const Panel &panel, const std::string &dir, const std::string &list_file, int n_threads, bool keep_line_no,
                  bool print_irregular, Cohort &out, int shard_index = 0, int shard_count = 1);

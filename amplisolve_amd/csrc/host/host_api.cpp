@@ -90,6 +90,28 @@ extern "C" int ampli_host_position(const ampli_host_cohort *h, int64_t p, char *
     return 0;
 }
 
+extern "C" int ampli_host_stream_chunks(const ampli_host_cohort *h, const char *aseq_dir, int n_threads, int keep_line_no, int64_t chunk_bytes,
+                                        ampli_host_chunk_fn fn, void *user)
+{
+    if (!h || !aseq_dir || !fn || chunk_bytes <= 0) return AMPLI_E_INVALID;
+    try {
+        static_assert(sizeof(Irregular) == 16, "Irregular is four 32-bit words");
+        ChunkStream cs(h->panel, list_count_files(aseq_dir, ""), n_threads, keep_line_no != 0, (size_t)chunk_bytes, 3);
+        for (Chunk *c; (c = cs.next()) != nullptr;) {
+            const int rc = fn(user, c->first, c->n, c->layout, c->P, c->E, c->prim, c->E ? c->ext : nullptr, c->dup_off.data(),
+                              c->E ? c->ext_pos.data() : nullptr, keep_line_no ? c->line_prim.data() : nullptr,
+                              (keep_line_no && c->E) ? c->line_ext.data() : nullptr, (const uint32_t *)c->irregular.data(),
+                              (int64_t)c->irregular.size());
+            cs.release(c);
+            if (rc != 0) return rc;
+        }
+    } catch (const Error &e) {
+        g_err = e.msg;
+        return e.code ? e.code : -1;
+    }
+    return 0;
+}
+
 extern "C" int ampli_host_write_error_table(const ampli_host_cohort *h, const float *rate, const uint8_t *code, const float *germ_val,
                                             const uint8_t *germ_present, const char *path)
 {

@@ -86,6 +86,63 @@ struct Dev {
     void sync() { check(api->sync(ctx), "ampli_sync"); }
 };
 
+// a device buffer that only ever grows (one per ring slot and kind)
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *ensure(Dev &dev, size_t bytes)
+    {
+        if (bytes > cap) {
+            if (p) dev.free(p);
+            p = nullptr;
+            cap = bytes + bytes / 8 + 256;
+            p = dev.alloc<char>(cap);
+        }
+        return p;
+    }
+};
+
+struct DevSlot {
+    DevBuf prim, ext, aux, mask;
+};
+
+size_t chunk_bytes_setting()
+{
+    // about this many bytes of 24-byte records per chunk (AMPLISOLVE_CHUNK_MB); three chunks are in flight
+    size_t mb = 128;
+    if (const char *e = getenv("AMPLISOLVE_CHUNK_MB")) mb = (size_t)std::max(1, atoi(e));
+    if (const char *e = getenv("AMPLISOLVE_CHUNK_BYTES")) return (size_t)std::max(1ll, atoll(e)); // tests: down to one sample per chunk
+    return mb << 20;
+}
+
+// upload one chunk into its ring slot and describe it for the kernels
+ampli_records upload_chunk(Dev &dev, DevSlot &ds, const Chunk &c, bool for_calling)
+{
+    const size_t rb = record_bytes(c.layout);
+    const size_t pb = (size_t)c.n * (size_t)c.P * rb, eb = (size_t)c.n * (size_t)c.E * rb;
+    void *d_prim = ds.prim.ensure(dev, pb);
+    dev.check(dev.api->copy_h2d(dev.ctx, d_prim, c.prim, pb), "ampli_copy_h2d");
+    ampli_records r;
+    memset(&r, 0, sizeof r);
+    r.recs = d_prim;
+    r.row_stride = c.P;
+    r.layout = c.layout;
+    r.n_samples = c.n;
+    r.E = c.E;
+    if (c.E > 0) {
+        void *d_ext = ds.ext.ensure(dev, eb);
+        dev.check(dev.api->copy_h2d(dev.ctx, d_ext, c.ext, eb), "ampli_copy_h2d");
+        r.ext = d_ext;
+        r.ext_stride = c.E;
+        const std::vector<uint32_t> &aux = for_calling ? c.ext_pos : c.dup_off;
+        void *d_aux = ds.aux.ensure(dev, aux.size() * sizeof(uint32_t));
+        dev.check(dev.api->copy_h2d(dev.ctx, d_aux, aux.data(), aux.size() * sizeof(uint32_t)), "ampli_copy_h2d");
+        if (for_calling) r.ext_pos = (const uint32_t *)d_aux;
+        else r.dup_off = (const uint32_t *)d_aux;
+    }
+    return r;
+}
+
 const char *kLine = "************************************************************************************************************************************";
 
 } // namespace
@@ -160,53 +217,93 @@ int run_error_estimation(const EeArgs &a)
         }
 
         double t1 = now_s();
-        Cohort co;
         const std::string list_name = interm + "/" + std::to_string(seed) + "_germline_count_list_original.txt"; // EE:442
         int threads = 0;
         if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
-        cohort_load(panel, a.germline_dir, writer ? list_name : std::string(), threads, false, true, co, sh ? sh->index : 0, sh ? sh->count : 1);
-        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.total_samples << " samples" << std::endl;
-        if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << co.first_sample + 1 << ".." << co.first_sample + co.S() << std::endl;
-        double t2 = now_s();
+        auto files = list_count_files(a.germline_dir, writer ? list_name : std::string());
+        const int total_samples = (int)files.size();
+        int first_sample = 0;
+        if (sh) files = shard_of_files(files, sh->index, sh->count, &first_sample);
+        const int S = (int)files.size();
+        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << total_samples << " samples" << std::endl;
+        if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << first_sample + 1 << ".." << first_sample + S << std::endl;
         std::cout << "Running function storeGermlineStatistics:" << std::endl;
 
         Dev dev;
         dev.open();
-        const int64_t P = co.P, R = co.R();
-        int32_t *d_recs = dev.upload(co.recs, (size_t)co.S() * R * 8);
-        uint32_t *d_dup = co.E ? dev.upload(co.dup_off.data(), co.dup_off.size()) : nullptr;
+        const int64_t P = panel.P();
         float *d_rate = dev.alloc<float>((size_t)P * 8), *d_germ = dev.alloc<float>((size_t)P * 4);
         uint8_t *d_code = dev.alloc<uint8_t>((size_t)P * 4), *d_gp = dev.alloc<uint8_t>((size_t)P * 4);
         int32_t *d_flags = dev.alloc<int32_t>(1);
         dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
+        // the accumulator table every chunk of samples is folded into (EE:1057-1481 + the record loop of EE:1484-2544)
+        void *d_accbuf = dev.alloc<char>(dev.api->acc_bytes(P));
+        ampli_acc_table acc;
+        dev.check(dev.api->acc_bind(d_accbuf, P, &acc), "ampli_acc_bind");
+        void *ev = nullptr;
+        dev.check(dev.api->event_create(&ev), "ampli_event_create");
+        struct EvGuard { const HipApi *api; void *ev; ~EvGuard() { if (ev) api->event_destroy(ev); } } evg{dev.api, ev};
+        DevSlot dslots[3];
+        int64_t n_lines = 0;
+        double parse_s = 0, wait_s = 0;
+        int chunks_done = 0;
+        // The cohort streams through in chunks of samples: while chunk k is uploaded and reduced into the table, the
+        // parser threads are already packing chunks k+1, k+2 into the other pinned buffers.  A depth beyond the fast
+        // kernel's integer envelope is only known afterwards (a flag): the cohort then streams a second time through
+        // the literal kernel.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            chunks_done = 0;
+            n_lines = 0;
+            if (S > 0) {
+                ChunkStream cs(panel, files, threads, false, chunk_bytes_setting(), 3);
+                for (Chunk *c; (c = cs.next()) != nullptr;) {
+                    if (attempt == 0) // the reference's own message, once per offending line (EE:1178-1181)
+                        for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl;
+                    const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, false);
+                    const bool fuse = c->last && !sh; // one device holds the whole panel: finalize in the last chunk's launch
+                    dev.check(dev.api->error_reduce_records(dev.ctx, &r, P, first_sample + c->first, C_value, cov, &acc, chunks_done > 0 ? 1 : 0,
+                                                            fuse ? d_rate : nullptr, fuse ? d_code : nullptr, nullptr, fuse ? d_germ : nullptr,
+                                                            fuse ? d_gp : nullptr, fuse ? d_flags : nullptr), "ampli_error_reduce_records");
+                    dev.check(dev.api->event_record(dev.ctx, ev), "ampli_event_record");
+                    const double w0 = now_s();
+                    dev.check(dev.api->event_sync(ev), "ampli_event_sync"); // the chunk's buffers are free again
+                    wait_s += now_s() - w0;
+                    n_lines += c->n_lines;
+                    ++chunks_done;
+                    if ((first_sample + c->first + c->n) / 50 > (first_sample + c->first) / 50)
+                        std::cout << "\tParsed successfully " << c->first + c->n << "/" << S << "  samples" << std::endl; // EE:1475-1478
+                    cs.release(c);
+                }
+                parse_s += cs.parse_seconds();
+            }
+            int32_t kflags = 0;
+            dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+            if (sh) hook(sh->or_flags(sh->user, &kflags), "or_flags");
+            if (!(kflags & AMPLI_FLAG_RERUN_GENERAL) || attempt == 1) break;
+            dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning"); // a depth beyond the fast kernel (on some shard): all stream again
+            dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
+        }
+        double t2 = now_s();
         std::cout << "Running function estimateThresholds: ";
         if (sh) {
-            // multi-process run: this shard's sums and germ-max pairs -> position-sliced exchange -> finalize of the own
-            // slice -> all-gather -> plane-major table on every shard (include/amplisolve_hip.h, "Position-sliced merge")
+            // multi-process run: this shard's table -> position-sliced exchange -> finalize of the own slice -> all-gather
+            // -> plane-major table on every shard (include/amplisolve_hip.h, "Position-sliced merge")
             const int n = sh->count;
             const int64_t L = dev.api->slice_len(P, n);
             void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             hook(sh->ee_buffers(sh->user, P, bufs), "ee_buffers");
             for (void *b : bufs)
                 if (!b) throw Error{AMPLI_E_INVALID, "shard hook ee_buffers returned a null buffer"};
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                if (co.S() > 0) {
-                    dev.check(dev.api->error_reduce_sliced(dev.ctx, d_recs, P, co.E, d_dup, co.S(), co.first_sample, C_value, cov, n,
-                                                           (double *)bufs[0], (float *)bufs[1]), "ampli_error_reduce_sliced");
-                } else { // a shard without samples: zero sums, "no qualifying record" germ-max pairs
-                    std::vector<float> none((size_t)n * 8 * L);
-                    for (int k = 0; k < n; ++k)
-                        for (int j = 0; j < 8; ++j)
-                            std::fill_n(none.begin() + ((size_t)k * 8 + j) * L, (size_t)L, j < 4 ? -1.0f : -INFINITY);
-                    dev.check(dev.api->memset_d(dev.ctx, bufs[0], 0, (size_t)n * 21 * L * sizeof(double)), "memset");
-                    dev.check(dev.api->copy_h2d(dev.ctx, bufs[1], none.data(), none.size() * sizeof(float)), "ampli_copy_h2d");
-                    dev.sync();
-                }
-                int32_t kflags = 0;
-                dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
-                hook(sh->or_flags(sh->user, &kflags), "or_flags");
-                if (!(kflags & AMPLI_FLAG_RERUN_GENERAL) || attempt == 1) break;
-                dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning"); // some shard met a depth beyond the fast kernel: all rerun
+            if (chunks_done > 0) {
+                dev.check(dev.api->acc_to_slices(dev.ctx, &acc, n, (double *)bufs[0], (float *)bufs[1]), "ampli_acc_to_slices");
+            } else { // a shard without samples: zero sums, "no qualifying record" germ-max pairs
+                std::vector<float> none((size_t)n * 8 * L);
+                for (int k = 0; k < n; ++k)
+                    for (int j = 0; j < 8; ++j)
+                        std::fill_n(none.begin() + ((size_t)k * 8 + j) * L, (size_t)L, j < 4 ? -1.0f : -INFINITY);
+                dev.check(dev.api->memset_d(dev.ctx, bufs[0], 0, (size_t)n * 21 * L * sizeof(double)), "memset");
+                dev.check(dev.api->copy_h2d(dev.ctx, bufs[1], none.data(), none.size() * sizeof(float)), "ampli_copy_h2d");
+                dev.sync();
             }
             hook(sh->ee_exchange(sh->user), "ee_exchange");
             dev.check(dev.api->error_finalize_slice(dev.ctx, P, n, sh->index, (const double *)bufs[2], (const float *)bufs[3], C_value, cov,
@@ -214,18 +311,8 @@ int run_error_estimation(const EeArgs &a)
             hook(sh->ee_gather(sh->user), "ee_gather");
             dev.check(dev.api->error_table_unslice(dev.ctx, P, n, bufs[5], d_rate, d_code, nullptr, d_germ, d_gp, d_flags),
                       "ampli_error_table_unslice");
-        } else {
-        // reduce + finalize fused (the whole panel is on this device)
-        dev.check(dev.api->error_estimate(dev.ctx, d_recs, P, co.E, d_dup, co.S(), C_value, cov, nullptr, d_rate, d_code, nullptr, d_germ,
-                                          d_gp, d_flags), "ampli_error_estimate");
-        int32_t kflags = 0;
-        dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
-        if (kflags & AMPLI_FLAG_RERUN_GENERAL) { // a depth beyond the fast kernel's integer envelope: literal kernel
-            dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning");
-            dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
-            dev.check(dev.api->error_estimate(dev.ctx, d_recs, P, co.E, d_dup, co.S(), C_value, cov, nullptr, d_rate, d_code, nullptr,
-                                              d_germ, d_gp, d_flags), "ampli_error_estimate");
-        }
+        } else if (chunks_done == 0) {
+            throw Error{AMPLI_E_INVALID, "no sample could be read from " + a.germline_dir};
         }
         std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
         std::vector<uint8_t> code((size_t)P * 4), gp((size_t)P * 4);
@@ -247,8 +334,8 @@ int run_error_estimation(const EeArgs &a)
         double t4 = now_s();
         std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
         if (getenv("AMPLISOLVE_TIMING"))
-            std::cerr << "TIMING panel " << t1 - t0 << "\nTIMING ingest " << t2 - t1 << " lines " << co.n_lines << "\nTIMING device " << t3 - t2
-                      << "\nTIMING write " << t4 - t3 << std::endl;
+            std::cerr << "TIMING panel " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done
+                      << " parse_busy " << parse_s << " device_wait " << wait_s << "\nTIMING finish " << t3 - t2 << "\nTIMING write " << t4 - t3 << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;
     } catch (const Error &e) {
@@ -263,10 +350,11 @@ int run_error_estimation(const EeArgs &a)
 namespace {
 
 struct CallRow {
-    int sample, line, alt;
-    int64_t rec;
+    int sample, line, alt; // sample: index in this process's range of the visit order
+    int64_t p;             // panel position
     double q_fw, q_bw;
     float af, af_fw, af_bw;
+    int rd, fw, bw, k_fw, k_bw; // the evidence of the call, as the kernel saw it
 };
 
 } // namespace
@@ -302,6 +390,7 @@ int run_variant_calling(const VcArgs &a)
         auto hook = [&](int rc, const char *what) { if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what}; };
         const std::string interm = a.output_dir + "/AmpliSolveVariantCalling_interm_files"; // VC:307
         mkdir_p(writer ? interm : a.output_dir);
+        const double t0 = now_s();
         Panel panel;
         std::vector<float> thr;
         panel_from_error_table(a.error_file, writer ? interm + "/dummyVCF_1.vcf" : std::string(), panel, thr); // VC:320
@@ -309,73 +398,97 @@ int run_variant_calling(const VcArgs &a)
         srand((unsigned)time(nullptr));
         const int seed = rand() % 1000;
         const std::string list_name = interm + "/" + std::to_string(seed) + "_tumour_count_list_original.txt"; // VC:332
-        Cohort co;
         int threads = 0;
         if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
-        cohort_load(panel, a.tumour_dir, writer ? list_name : std::string(), threads, true, true, co, sh ? sh->index : 0, sh ? sh->count : 1);
-        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << co.total_samples << " samples" << std::endl;
-        if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << co.first_sample + 1 << ".." << co.first_sample + co.S() << std::endl;
+        auto files = list_count_files(a.tumour_dir, writer ? list_name : std::string());
+        const int total_samples = (int)files.size();
+        int first_sample = 0;
+        if (sh) files = shard_of_files(files, sh->index, sh->count, &first_sample);
+        const int T = (int)files.size();
+        std::cout << "\nRunning function storeList: " << list_name << " stored with success. It contains " << total_samples << " samples" << std::endl;
+        if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << first_sample + 1 << ".." << first_sample + T << std::endl;
         std::cout << "\nRunning function callVariants...." << std::endl;
 
-        const int64_t P = co.P, R = co.R();
-        const int T = co.S();
+        const double t1 = now_s();
+        const int64_t P = panel.P();
         std::vector<CallRow> rows;
+        int64_t n_lines = 0;
+        double parse_s = 0;
+        int chunks_done = 0;
         if (T > 0 || !sh) { // a shard of a multi-process run may hold no tumour file
             Dev dev;
             dev.open();
-            int32_t *d_recs = dev.upload(co.recs, (size_t)T * R * 8);
-            uint32_t *d_ext = co.E ? dev.upload(co.ext_pos.data(), co.ext_pos.size()) : nullptr;
             float *d_thr = dev.upload(thr.data(), thr.size());
             uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
-            uint8_t *d_mask = dev.alloc<uint8_t>((size_t)T * R);
             unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
-            int64_t cap = std::max<int64_t>(1 << 16, (int64_t)T * R / 16);
-            ampli_call *d_calls = nullptr;
-            bool done = false;
-            std::string why = "call list still overflowing";
-            for (int attempt = 0; attempt < 6 && !done; ++attempt) {
-                cap -= cap % AMPLI_CALL_SHARDS;
-                const int64_t per = cap / AMPLI_CALL_SHARDS;
-                if (d_calls) dev.free(d_calls); // the previous attempt's list
-                d_calls = dev.alloc<ampli_call>((size_t)cap);
-                dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
-                dev.check(dev.api->poisson_call(dev.ctx, d_recs, P, co.E, d_ext, T, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask,
-                                                d_calls, cap, d_n, nullptr, nullptr), "ampli_poisson_call");
-                int32_t kflags = 0;
-                dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
-                if (kflags & AMPLI_FLAG_QUEUE_OVERFLOW) { // more survivors than the default queue holds: size it for the worst case
-                    dev.check(dev.api->set_queue_items(dev.ctx, (int64_t)T * R * 3), "ampli_set_queue_items");
-                    why = "prefilter queue still overflowing";
-                    continue;
-                }
-                std::vector<unsigned long long> n(AMPLI_CALL_COUNTER_WORDS);
-                dev.download(n.data(), d_n, n.size());
-                dev.sync();
-                unsigned long long worst = 0, total = 0;
-                for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
-                    worst = std::max(worst, n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE]);
-                    total += n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
-                }
-                if ((int64_t)worst > per) {
-                    // a segment overflowed.  Which segment a call lands in depends on the order the workgroups ran in, so
-                    // the rerun is sized with headroom: every segment could hold ALL calls of this pass, capped at the
-                    // number of (record, alt) pairs there are
-                    cap = (int64_t)std::min<unsigned long long>((unsigned long long)T * R * 3, std::max(total, 2 * worst)) * AMPLI_CALL_SHARDS;
-                    why = "call list still overflowing";
-                    continue;
-                }
-                for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
-                    const size_t cnt = (size_t)n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
-                    std::vector<ampli_call> calls(cnt);
-                    if (cnt) dev.download(calls.data(), d_calls + (size_t)k * per, cnt);
+            DevSlot dslots[3];
+            // tumour files are independent given the error table: they stream through in chunks (parsing of the next
+            // chunks overlaps upload + kernels of this one); only the emitted calls come back
+            ChunkStream cs(panel, files, threads, true, chunk_bytes_setting(), 3);
+            for (Chunk *c; (c = cs.next()) != nullptr;) {
+                for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl; // VC:762-765
+                const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, true);
+                const int64_t R = P + c->E;
+                uint8_t *d_mask = (uint8_t *)dslots[c->slot].mask.ensure(dev, (size_t)c->n * R + 4);
+                int64_t cap = std::max<int64_t>(1 << 16, (int64_t)c->n * R / 16);
+                ampli_call *d_calls = nullptr;
+                bool done = false;
+                std::string why = "call list still overflowing";
+                for (int attempt = 0; attempt < 6 && !done; ++attempt) {
+                    cap -= cap % AMPLI_CALL_SHARDS;
+                    const int64_t per = cap / AMPLI_CALL_SHARDS;
+                    if (d_calls) dev.free(d_calls); // the previous attempt's list
+                    d_calls = dev.alloc<ampli_call>((size_t)cap);
+                    dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
+                    dev.check(dev.api->poisson_call_records(dev.ctx, &r, P, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask, d_calls, cap, d_n,
+                                                            nullptr, nullptr), "ampli_poisson_call_records");
+                    int32_t kflags = 0;
+                    dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+                    if (kflags & AMPLI_FLAG_QUEUE_OVERFLOW) { // more survivors than the default queue holds: size it for the worst case
+                        dev.check(dev.api->set_queue_items(dev.ctx, (int64_t)c->n * R * 3), "ampli_set_queue_items");
+                        why = "prefilter queue still overflowing";
+                        continue;
+                    }
+                    std::vector<unsigned long long> n(AMPLI_CALL_COUNTER_WORDS);
+                    dev.download(n.data(), d_n, n.size());
                     dev.sync();
-                    for (auto &c : calls)
-                        rows.push_back(CallRow{c.sample, co.line_no[(size_t)c.sample * R + c.record], c.alt, c.record, c.q_fw, c.q_bw, c.af, c.af_fw, c.af_bw});
+                    unsigned long long worst = 0, total = 0;
+                    for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
+                        worst = std::max(worst, n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE]);
+                        total += n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
+                    }
+                    if ((int64_t)worst > per) {
+                        // a segment overflowed.  Which segment a call lands in depends on the order the workgroups ran in, so
+                        // the rerun is sized with headroom: every segment could hold ALL calls of this pass, capped at the
+                        // number of (record, alt) pairs there are
+                        cap = (int64_t)std::min<unsigned long long>((unsigned long long)c->n * R * 3, std::max(total, 2 * worst)) * AMPLI_CALL_SHARDS;
+                        why = "call list still overflowing";
+                        continue;
+                    }
+                    for (int k = 0; k < AMPLI_CALL_SHARDS; ++k) {
+                        const size_t cnt = (size_t)n[(size_t)k * AMPLI_CALL_COUNTER_STRIDE];
+                        std::vector<ampli_call> calls(cnt);
+                        if (cnt) dev.download(calls.data(), d_calls + (size_t)k * per, cnt);
+                        dev.sync();
+                        for (auto &cl : calls) {
+                            const bool prim = cl.record < P;
+                            const int line = prim ? c->line_prim[(size_t)cl.sample * P + cl.record] : c->line_ext[(size_t)cl.sample * c->E + (cl.record - P)];
+                            const int64_t pp = prim ? (int64_t)cl.record : (int64_t)c->ext_pos[(size_t)(cl.record - P)];
+                            rows.push_back(CallRow{c->first + cl.sample, line, cl.alt, pp, cl.q_fw, cl.q_bw, cl.af, cl.af_fw, cl.af_bw, cl.rd, cl.fw,
+                                                   cl.bw, cl.k_fw, cl.k_bw});
+                        }
+                    }
+                    done = true;
                 }
-                done = true;
+                if (d_calls) dev.free(d_calls);
+                if (!done) throw Error{AMPLI_E_CAPACITY, "variant calling did not complete a pass: " + why};
+                n_lines += c->n_lines;
+                ++chunks_done;
+                cs.release(c);
             }
-            if (!done) throw Error{AMPLI_E_CAPACITY, "variant calling did not complete a pass: " + why};
+            parse_s = cs.parse_seconds();
         }
+        const double t2 = now_s();
         // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
         std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
             if (x.sample != y.sample) return x.sample < y.sample;
@@ -395,23 +508,23 @@ int run_variant_calling(const VcArgs &a)
         output << "Filename\tChrom\tPosition\tSubtitution\tRD\tRD_fw\tRD_bw\tAF\tReads_fw\tReads_bw\tAF_fw\tAF_bw\tAmpliconEdge_StrandBias\tFisherPvalue\tQscore_fw\tQscore_bw\tReadTier\tGermlineInfo\tMaxGermlineAF\t10merDownstream\t10merUpstream\tHomopolymerFlag" << std::endl; // VC:669
         size_t ri = 0;
         for (int t = 0; t < T; ++t) {
-            std::ofstream vcf(a.output_dir + "/" + co.names[t] + ".vcf"); // VC:679
+            const std::string &sample_name = files[(size_t)t].second;
+            std::ofstream vcf(a.output_dir + "/" + sample_name + ".vcf"); // VC:679
             time_t now = time(0);
             char *dt = ctime(&now);
             vcf << "##fileformat=VCF-like\n##fileDate=" << dt
                 << "##source=AmpliSolveVariantCalling\n##reference=Not_Specified_here\n##phasing=Not_Specified_here\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##FILTER=<ID=XXXXXXXXX,Description='XXXXXXXXX'>\n##INFO=<ID=RD,Number=1,Type=Integer,Description='Total Read Depth'>\n##SAMPLE=<ID=Not_Specified_here,SampleName="
-                << co.names[t]
+                << sample_name
                 << ">\n##INFO=<ID=AF,Number=.,Type=Float,Description='Allele Frequency'>\n##INFO=<ID=SR,Number=1,Type=String,Description='Supporting Reads'>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"
                 << std::endl; // VC:688
             if ((t + 1) % 50 == 0) std::cout << "\tParsed successfully " << t + 1 << "/" << T << "  samples" << std::endl;
             for (; ri < rows.size() && rows[ri].sample == t; ++ri) {
                 const CallRow &c = rows[ri];
-                const int32_t *rec = co.recs + ((size_t)t * R + c.rec) * 8;
-                const int64_t p = c.rec < P ? c.rec : (int64_t)co.ext_pos[c.rec - P];
+                const int64_t p = c.p;
                 const std::string &chrom = panel.chroms[panel.pos_chrom[p]];
                 const int pos = panel.pos_coord[p];
-                const int FW = rec[0] + rec[1] + rec[2] + rec[3], BW = rec[4] + rec[5] + rec[6] + rec[7], RD = FW + BW;
-                const int alt_fw = rec[c.alt], alt_bw = rec[4 + c.alt];
+                const int FW = c.fw, BW = c.bw, RD = c.rd; // VC:760-761 and the RD column
+                const int alt_fw = c.k_fw, alt_bw = c.k_bw;
                 const char refc = "ACGT"[panel.ref_code[p]], altc = "ACGT"[c.alt];
                 const std::string Flag_Dup = panel.dup[p] ? "YES" : "NO";
                 const double pf = fisher_two_sided(RD - BW, BW, alt_fw, alt_bw);      // VC:902
@@ -445,7 +558,7 @@ int run_variant_calling(const VcArgs &a)
                 vcf << chrom << "\t" << pos << "\t" << id << "\t" << refc << "\t" << altc << "\t" << Q << "\t" << filter << "\t" << c.af << ";" << RD
                     << ";" << alt_fw + alt_bw << std::endl; // VC:1040 / 1062
                 // VC:1066 -- std::setprecision(4) is set mid-row and sticks for every later row of the file
-                output << co.names[t] << "\t" << chrom << "\t" << pos << "\t" << refc << "->" << altc << "\t" << RD << "\t" << FW << "\t" << BW << "\t"
+                output << sample_name << "\t" << chrom << "\t" << pos << "\t" << refc << "->" << altc << "\t" << RD << "\t" << FW << "\t" << BW << "\t"
                        << c.af << "\t" << alt_fw << "\t" << alt_bw << "\t" << c.af_fw << "\t" << c.af_bw << "\t" << Flag_Dup << "_" << Flag_Fisher
                        << "\t" << pf << "\t" << std::setprecision(4) << c.q_fw << "\t" << std::setprecision(4) << c.q_bw << "\t" << Flag_Tier << "\t"
                        << GermlineFlag << "\t" << MaxGermlineFlag << "\t" << down << "\t" << up << "\t" << homo << std::endl;
@@ -471,6 +584,9 @@ int run_variant_calling(const VcArgs &a)
                 if (all.fail()) throw Error{AMPLI_E_INVALID, "could not write " + summary};
             }
         }
+        if (getenv("AMPLISOLVE_TIMING"))
+            std::cerr << "TIMING table " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done << " parse_busy "
+                      << parse_s << " calls " << rows.size() << "\nTIMING annotate+write " << now_s() - t2 << std::endl;
         std::cout << "\nAmpliSolveVariantCalling execution was successful. The results can be found at : " << summary << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;

@@ -5,7 +5,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import AmpliError, host_lib
+from ._lib import CHUNK_FN, AmpliError, host_lib
 
 
 def _b(s):
@@ -73,6 +73,33 @@ class HostCohort:
         if rc != 0:
             raise AmpliError(self._lib.ampli_host_last_error().decode())
 
+    def stream_chunks(self, aseq_dir, chunk_bytes=128 << 20, threads=0, keep_line_no=False):
+        """The directory as the command lines ingest it (ampli_host_stream_chunks): a list of chunks, each a dict with
+        first, n, layout (0 = int32, 2 = 24-bit), E, prim / ext (raw uint8 [n][P or E][record bytes]), dup_off, ext_pos,
+        line_prim / line_ext, irregular (int64 [k][4]: sample in chunk, record slot, occurrence, RD)."""
+        P = self.P
+        out = []
+
+        def cb(user, first, n, layout, P_, E, prim, ext, dup_off, ext_pos, line_prim, line_ext, irr, n_irr):
+            rb = {0: 32, 1: 16, 2: 24}[layout]
+
+            def arr(ptr, count, dtype):
+                if not ptr or count == 0:
+                    return np.zeros(count, dtype)
+                return np.frombuffer((C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype).copy()
+
+            out.append(dict(first=first, n=n, layout=layout, E=E, prim=arr(prim, n * P_ * rb, np.uint8).reshape(n, P_, rb),
+                            ext=arr(ext, n * E * rb, np.uint8).reshape(n, E, rb), dup_off=arr(dup_off, P_ + 1, np.uint32),
+                            ext_pos=arr(ext_pos, E, np.uint32), line_prim=arr(line_prim, n * P_, np.int32).reshape(n, P_) if line_prim else None,
+                            line_ext=arr(line_ext, n * E, np.int32).reshape(n, E) if line_ext else None,
+                            irregular=arr(irr, n_irr * 4, np.uint32).reshape(n_irr, 4).astype(np.int64)))
+            return 0
+
+        rc = self._lib.ampli_host_stream_chunks(self.h, _b(aseq_dir), threads, int(keep_line_no), chunk_bytes, CHUNK_FN(cb), None)
+        if rc != 0:
+            raise AmpliError(f"ampli_host_stream_chunks ({rc}): {self._lib.ampli_host_last_error().decode()}")
+        return out
+
     def close(self):
         if self.h:
             self._lib.ampli_host_cohort_free(self.h)
@@ -112,3 +139,19 @@ def sample_order(aseq_dir):
     if n < 0:
         raise AmpliError(lib.ampli_host_last_error().decode())
     return buf.value.decode().split("\n")[:n]
+
+
+def unpack_records(raw, layout):
+    """raw uint8 [..., record bytes] in a device layout -> int32 [..., 8] of the interchange layout (absent: INT32_MIN in field 0)."""
+    raw = np.ascontiguousarray(raw)
+    lead = raw.shape[:-1]
+    if layout == 0:
+        return raw.view(np.int32).reshape(lead + (8,)).copy()
+    if layout == 1:
+        v = raw.view(np.uint16).reshape(lead + (8,)).astype(np.int32)
+        v[..., 0] = np.where(v[..., 0] == 0xFFFF, np.iinfo(np.int32).min, v[..., 0])
+        return v
+    b = raw.reshape(lead + (8, 3)).astype(np.int32)
+    v = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+    v[..., 0] = np.where(v[..., 0] == 0xFFFFFF, np.iinfo(np.int32).min, v[..., 0])
+    return v

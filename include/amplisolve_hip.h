@@ -103,6 +103,7 @@ int ampli_memset_d(ampli_ctx *ctx, void *d_dst, int byte, size_t bytes);        
 int ampli_event_create(void **ev);
 int ampli_event_destroy(void *ev);
 int ampli_event_record(ampli_ctx *ctx, void *ev);
+int ampli_event_sync(void *ev);                                         /* hipEventSynchronize */
 int ampli_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms); /* synchronises on ev_stop */
 
 /*
@@ -257,6 +258,9 @@ int ampli_slice_bytes(int64_t P, int32_t n_slices, size_t *sums_bytes, size_t *g
 int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
                               int32_t S, int32_t first_sample, float C, int32_t coverage_cutoff, int32_t n_slices,
                               double *d_sums, float *d_gm);
+/* a shard's accumulator table (e.g. built chunk by chunk with ampli_error_reduce_records) -> the slice-major exchange
+ * buffers ampli_error_reduce_sliced would have written */
+int ampli_acc_to_slices(ampli_ctx *ctx, const ampli_acc_table *d_acc, int32_t n_slices, double *d_sums, float *d_gm);
 int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_slices, int32_t slice_index,
                                const double *d_sum_slice, const float *d_gm_recv, float C, int32_t coverage_cutoff,
                                void *d_block);

@@ -66,6 +66,19 @@ int ampli_host_position(const ampli_host_cohort *h, int64_t p, char *chrom_out, 
 /* sample names of the .ASEQ files of dir in visit order, newline separated; returns the count */
 int ampli_host_sample_order(const char *dir, char *out, int64_t cap);
 
+/* ---- the cohort as the command lines see it: a stream of chunks of consecutive samples, already in the device record
+ * layout (what ampli_records of include/amplisolve_hip.h describes).  The callback gets one chunk at a time, in visit
+ * order, while the next ones are being parsed; its pointers are valid until it returns.  layout: AMPLI_RECORDS_U24, or
+ * AMPLI_RECORDS_I32 for a chunk holding a count above 2^24 - 2.  prim [n][P] records, ext [n][E] records (E, dup_off,
+ * ext_pos are the CHUNK's own); line_prim / line_ext with keep_line_no; irregular: n_irregular x {sample in chunk, record
+ * slot, occurrence, RD column} for lines with RD != A+C+G+T.  A negative strand count (reverse above total) or a count
+ * beyond int32 ends the stream with AMPLI_E_RANGE.  Return non-zero from the callback to stop. */
+typedef int (*ampli_host_chunk_fn)(void *user, int32_t first_sample, int32_t n_samples, int32_t layout, int64_t P, int64_t E,
+                                   const void *prim, const void *ext, const uint32_t *dup_off, const uint32_t *ext_pos,
+                                   const int32_t *line_prim, const int32_t *line_ext, const uint32_t *irregular, int64_t n_irregular);
+int ampli_host_stream_chunks(const ampli_host_cohort *panel, const char *aseq_dir, int n_threads, int keep_line_no,
+                             int64_t chunk_bytes, ampli_host_chunk_fn fn, void *user);
+
 /* ---- the error table on disk (EE:2546-2944 writer, VC:430-576 reader) ---- */
 int ampli_host_write_error_table(const ampli_host_cohort *h, const float *rate /*[2][4][P]*/, const uint8_t *code /*[4][P]*/,
                                  const float *germ_val /*[4][P]*/, const uint8_t *germ_present /*[4][P]*/, const char *path);
