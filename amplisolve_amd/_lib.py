@@ -118,6 +118,8 @@ CHUNK_FN = C.CFUNCTYPE(C.c_int, vp, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp,
 HOST_SYMBOLS = {
     "ampli_host_synth_fill": (C.c_int, [vp, i64, i32, i32, u64, i32, i32]),
     "ampli_host_synth_ref": (C.c_int, [vp, i64, u64]),
+    "ampli_host_synth_write_panel": (C.c_int, [C.c_char_p, C.c_char_p, i64, u64]),
+    "ampli_host_synth_write_aseq": (i64, [C.c_char_p, C.c_char_p, i64, i32, i32, u64, i32, i32, i32]),
     "ampli_host_text_roundtrip_batch": (None, [vp, i64, vp]),
     "ampli_host_af_limit": (i32, [i32]),
     "ampli_host_af_limit_batch": (None, [vp, i64, vp]),

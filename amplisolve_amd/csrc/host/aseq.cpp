@@ -437,7 +437,8 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
     : im(new Impl(panel))
 {
     im->files = std::move(files);
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    // default: the cores this process may run on, at most 16 (one GPU's share of a node; AMPLISOLVE_THREADS overrides)
+    if (n_threads <= 0) n_threads = std::min(16, (int)std::thread::hardware_concurrency());
     im->n_threads = std::max(1, n_threads);
     im->keep_line = keep_line_no;
     const int64_t P = panel.P();

@@ -172,6 +172,23 @@ class SlicedMerger:
         self._a2a_tmp = None if self.native else torch.zeros(world * world * 8 * L, dtype=torch.float32, **z)
         assert sums_bytes == self.sums[0].numel() * 8 and gm_bytes == self.gm[0].numel() * 4
 
+    def probe(self):
+        """The three collectives of the exchange on tiny tensors: raises where the runtime lacks one (it does so at the
+        call, identically on every rank), so that all ranks can agree on a fall-back BEFORE the pipeline starts."""
+        import torch
+        import torch.distributed as dist
+
+        if not self.native:
+            return
+        dev, w = self.sums[0].device, self.world
+        a = torch.zeros(w * 4, dtype=torch.float64, device=dev)
+        dist.reduce_scatter_tensor(torch.zeros(4, dtype=torch.float64, device=dev), a, op=dist.ReduceOp.SUM, group=self.group)
+        b = torch.zeros(w * 4, dtype=torch.float32, device=dev)
+        dist.all_to_all_single(torch.zeros_like(b), b, group=self.group)
+        c = torch.zeros(8, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(torch.zeros(w * 8, dtype=torch.uint8, device=dev), c, group=self.group)
+        torch.cuda.synchronize(dev)
+
     def start_exchange(self, slot: int):
         import torch.distributed as dist
 

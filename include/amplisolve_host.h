@@ -25,6 +25,12 @@ int ampli_host_synth_fill(int32_t *recs /*[n_samples][P][8]*/, int64_t P, int32_
                           int32_t first_sample, uint64_t seed, int32_t depth, int32_t tumour);
 int ampli_host_synth_ref(uint8_t *ref_code /*[P]*/, int64_t P, uint64_t seed);
 
+/* the same panel as files: BED + "chrom pos base" table, and one .PILEUP.ASEQ per sample (<dir>/<prefix>NNNNN.PILEUP.ASEQ)
+ * with exactly the counts ampli_host_synth_fill / ampli_synth_fill produce; returns the bytes of text written (< 0: error) */
+int ampli_host_synth_write_panel(const char *bed_path, const char *refbases_path, int64_t P, uint64_t seed);
+int64_t ampli_host_synth_write_aseq(const char *dir, const char *prefix, int64_t P, int32_t n_samples, int32_t first_sample,
+                                    uint64_t seed, int32_t depth, int32_t tumour, int32_t n_threads);
+
 /* ---- scalar helpers of csrc/ampli_math.h compiled for the host (formatting, unit checks) ---- */
 void ampli_host_text_roundtrip_batch(const float *in, int64_t n, float *out);
 int32_t ampli_host_af_limit(int32_t d);

@@ -2,8 +2,8 @@
 """Turn gpurun_out/prof_final/ (tools/collect_profiles.sh) into the committed summaries under profiles/<round>/."""
 import collections, csv, glob, json, os, shutil, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = "gpurun_out/prof_final"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r02"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
@@ -26,7 +26,13 @@ for k, d in pm.items():
         row["hbm_write_bytes"] = m.get("WRITE_SIZE", 0.0) * 1024
         row["hbm_bytes_per_launch"] = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
     out[k] = row
-json.dump(out, open(f"{dst}/pmc_summary.json", "w"), indent=1, sort_keys=True)
+import hashlib
+h = hashlib.sha256()
+for f in ("ampli_kernels.hip", "ampli_math.h"):
+    h.update(open(os.path.join("amplisolve_amd", "csrc", f), "rb").read())
+# bench.py only quotes these counters while the kernel source is the one they were collected on
+json.dump({"kernel_source_sha256": h.hexdigest(), "command": "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0",
+           "kernels": out}, open(f"{dst}/pmc_summary.json", "w"), indent=1, sort_keys=True)
 for name in ("bench_default.log", "bench_under_trace.log"):
     p = f"{src}/{name}"
     if os.path.exists(p):
