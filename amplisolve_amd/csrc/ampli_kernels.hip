@@ -1449,8 +1449,29 @@ __device__ __forceinline__ void pc_block_map(const unsigned b, const unsigned gy
     y = slot % gy;
 }
 
+// Queue hand-over of a wave's staged items: ONE returning atomic on the shard's counter for up to PC_STAGE items (a
+// returning atomic costs a wave 1-3 us under load; one per (row, alternative) with a survivor, as a first version did,
+// kept ~40 % of the waves waiting at some point of their short lives), then a coalesced copy LDS -> HBM.
+constexpr int PC_STAGE = 64; // items a wave stages before it must hand over (64 lanes x at most one item per (row, alt))
+
+__device__ __forceinline__ void pc_flush(const PcItem *__restrict__ st, const int count, const int lane, PcItem *__restrict__ queue,
+                                         const long long queue_per_shard, unsigned long long *__restrict__ queue_n, const unsigned shard,
+                                         int *__restrict__ flags)
+{
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&queue_n[shard * AMPLI_CALL_COUNTER_STRIDE], (unsigned long long)count);
+    base = __shfl(base, 0);
+    // 40-byte items as 10 dwords each: lane l copies dwords l, l + 64, ...
+    const unsigned *__restrict__ src = (const unsigned *)st;
+    const long long room = queue_per_shard - (long long)base; // items that still fit (<= 0: none)
+    const int fit = room >= count ? count : (room > 0 ? (int)room : 0);
+    unsigned *__restrict__ dst = (unsigned *)(queue + (size_t)shard * queue_per_shard + base);
+    for (int i = lane; i < fit * 10; i += 64) dst[i] = src[i];
+    if (fit < count && lane == 0) atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
+}
+
 template <int LAY>
-__global__ __launch_bounds__(256) void poisson_stream_kernel(
+__global__ __launch_bounds__(256, 8) void poisson_stream_kernel(
     const RecView rv, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const int rows_per_wave, const unsigned gy, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
     const unsigned char *__restrict__ ref_code,
@@ -1458,12 +1479,24 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     unsigned char *__restrict__ call_mask, int *__restrict__ flags, unsigned long long *__restrict__ n_calls)
 {
     constexpr int RB = rec_bytes_of<LAY>();
+    __shared__ PcItem stage[4][PC_STAGE];
+    int staged = 0; // wave-uniform
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long R = P + E;
     // the call-list counters are reset here: only the drain kernel, which starts after this one has finished,
     // appends to the list
     if (n_calls && blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) n_calls[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
+    // The call mask starts as "no call" (the drain ORs bits in).  Every wave of the grid clears an equal, CONTIGUOUS share
+    // of the mask's bytes -- whole 128-byte lines, one store instruction per 256 bytes -- rather than the 64 scattered
+    // bytes per row that belong to its own records (partial-line writes cost the streaming kernel ~10 % in the loop).
+    {
+        const size_t m4 = ((size_t)T * (size_t)R + 3) / 4;       // the mask as dwords (the buffer is padded to a multiple of 4)
+        const size_t share = (size_t)rows_per_wave * 16;         // dwords per wave: grid waves x share >= m4
+        const size_t w0 = ((size_t)blockIdx.x * 4 + wave) * share;
+        const size_t w1 = w0 + share < m4 ? w0 + share : m4;
+        for (size_t o = w0 + lane; o < w1; o += 64) ((unsigned *)call_mask)[o] = 0u;
+    }
     unsigned tile, y;
     pc_block_map(blockIdx.x, gy, tile, y);
     const long long r_raw = (long long)tile * 64 + lane;
@@ -1489,7 +1522,6 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
     const size_t step = (size_t)(r < P ? rv.row_stride : rv.ext_stride) * RB; // bytes between consecutive samples
     const char *__restrict__ q = r < P ? rv.base + ((size_t)t0 * (size_t)rv.row_stride + (size_t)r) * RB
                                        : rv.ext + ((size_t)t0 * (size_t)rv.ext_stride + (size_t)(r - P)) * RB;
-    unsigned char *__restrict__ mrow = call_mask + (size_t)t0 * R + r;
     RawRec<LAY> nx = rec_load_at<LAY>(q);
     for (int dt = 0; dt < nt_rows; ++dt) {
         int4 r0v, r1v;
@@ -1498,7 +1530,6 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
             q += step;
             nx = rec_load_at<LAY>(q);
         }
-        if (valid) mrow[(size_t)dt * R] = 0; // this record's byte of the call mask starts as "no call" (the drain ORs bits in)
         const int fw[4] = {r0v.x, r0v.y, r0v.z, r0v.w};
         const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
         const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
@@ -1517,34 +1548,30 @@ __global__ __launch_bounds__(256) void poisson_stream_kernel(
             const bool skip_bw = exact && (unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)bw[nt] <= c_bw * te[1][nt];
             if (live && nt != ref && !skip_fw && !skip_bw) pushmask |= 1u << nt;
         }
-        if (__any(pushmask != 0)) { // rare
+        if (__any(pushmask != 0)) { // rare: stage the items in LDS, one slot range per wave
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const bool push = (pushmask >> nt) & 1;
                 const unsigned long long bal = __ballot(push);
                 if (bal) {
                     const int n = __popcll(bal);
-                    unsigned long long base = 0;
-                    if (lane == (int)__ffsll((long long)bal) - 1)
-                        base = atomicAdd(&queue_n[shard * AMPLI_CALL_COUNTER_STRIDE], (unsigned long long)n);
-                    base = __shfl(base, (int)__ffsll((long long)bal) - 1);
-                    if (push) {
-                        const long long i = (long long)base +
-                                            __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-                        if (i < queue_per_shard) {
-                            PcItem it;
-                            it.sample = t0 + dt; it.record_alt = (int)r | (nt << 30);
-                            it.k_fw = fw[nt]; it.k_bw = bw[nt]; it.FW = FW; it.BW = BW; it.rd = RD;
-                            it.e_fw = te[0][nt]; it.e_bw = te[1][nt]; it.pad = 0;
-                            queue[(size_t)shard * queue_per_shard + i] = it;
-                        } else {
-                            atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
-                        }
+                    if (staged + n > PC_STAGE) { // wave-uniform: no room for this batch -> hand the staged items over first
+                        pc_flush(stage[wave], staged, lane, queue, queue_per_shard, queue_n, shard, flags);
+                        staged = 0;
                     }
+                    if (push) {
+                        PcItem it;
+                        it.sample = t0 + dt; it.record_alt = (int)r | (nt << 30);
+                        it.k_fw = fw[nt]; it.k_bw = bw[nt]; it.FW = FW; it.BW = BW; it.rd = RD;
+                        it.e_fw = te[0][nt]; it.e_bw = te[1][nt]; it.pad = 0;
+                        stage[wave][staged + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = it;
+                    }
+                    staged += n;
                 }
             }
         }
     }
+    if (staged) pc_flush(stage[wave], staged, lane, queue, queue_per_shard, queue_n, shard, flags);
 }
 
 // Two adjacent lanes per queued item, one per strand.  The scorer here is kf_gammaq's series branch in its
@@ -2176,8 +2203,14 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
         // many short waves that keep every CU fed through the tail; the thresholds of a tile are shared through the
         // XCD's L2 by the mapping of poisson_stream_kernel, so short waves no longer cost re-reads over the fabric.
         const long long tiles = (R + 63) / 64, tiles8 = (tiles + 7) / 8 * 8;
-        int rpw = ctx->pc_rows_per_wave > 0 ? ctx->pc_rows_per_wave : 4;
-        if (rpw > T) rpw = T;
+        // rows per wave: long-lived waves stream best from cold HBM (config 3 in bench.py's loop: 24 rows 0.062 ms, 8 rows
+        // 0.065 ms, 4 rows 0.068 ms), as long as the launch still fills the chip: halve them while it would leave more than
+        // half of the wave slots empty
+        int rpw = ctx->pc_rows_per_wave > 0 ? ctx->pc_rows_per_wave : 24;
+        if (rpw > (T + 3) / 4) rpw = (T + 3) / 4;
+        if (ctx->pc_rows_per_wave <= 0)
+            while (rpw > 2 && tiles * 4 * ((T + 4 * rpw - 1) / (4 * rpw)) < (long long)ctx->n_cu * 16) rpw = (rpw + 1) / 2;
+        if (rpw < 1) rpw = 1;
         long long gy = (T + 4 * rpw - 1) / (4 * rpw);
         while (tiles8 * gy > 0x7fffffffll) { rpw *= 2; gy = (T + 4 * rpw - 1) / (4 * rpw); } // gridDim.x limit
         // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),

@@ -142,7 +142,8 @@ AMPLI_FN double ampli_kf_gammaq_cf(double s, double z)
 // one fused multiply-add per term on the critical path instead of an IEEE division (~10 dependent operations), every
 // term positive (no cancellation), A / D in [1, 100]; A, D and z^n are rescaled by an exact power of two every 16 terms
 // ((s+n)^16 < 2^500 for every int32 count).  Differences from ampli_kf_gammap_series: (i) rounding, ~1e-14 relative;
-// (ii) the reference stops at the first term with x/sum < 1e-14 -- the terms it leaves out add < ~1e-13 of the sum.
+// (ii) the reference stops at the first term with x/sum < 1e-14 -- the terms it leaves out add < ~1e-13 of the sum
+// (this form stops, between runs of 16 terms, only once a term is below 2^-60 of the sum).
 // Both are eight orders of magnitude inside the 1e-6 tolerance on p.  What is NOT optional is the cap at n = 99:
 // for z close to s the series has not converged by then and the truncation is part of the reference's result.
 AMPLI_FN double ampli_kf_gammap_series_nodiv(double s, double z)
@@ -158,6 +159,9 @@ AMPLI_FN double ampli_kf_gammap_series_nodiv(double s, double z)
             A = fma(A, t, zp);
             D *= t;
         }
+        // z < s: every further term is smaller than the last one (zp / D), so once that is below 2^-60 of the sum the
+        // at most 83 terms still to come cannot change the double any more
+        if (zp < A * 8.673617379884035e-19) break;
         int e;
         (void)frexp(D, &e);
         A = ldexp(A, -e); D = ldexp(D, -e); zp = ldexp(zp, -e);

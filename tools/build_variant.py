@@ -1,0 +1,40 @@
+"""Build experimental variants of libamplisolve_hip.so WITHOUT touching the shipped translation unit: a variant is a list
+of (old text, new text) substitutions applied to a copy of csrc/ampli_kernels.hip, compiled into _variants/<name>.so.
+Run a tool against one with AMPLISOLVE_HIP_LIB=_variants/<name>.so.   usage: python tools/build_variant.py NAME [NAME ...]"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "amplisolve_amd", "csrc", "ampli_kernels.hip")
+OUT = os.path.join(ROOT, "_variants")
+
+V = {
+    # poisson_stream at whatever occupancy the register allocator picks (shipped: __launch_bounds__(256, 8))
+    "lb256": [("template <int LAY>\n__global__ __launch_bounds__(256, 8) void poisson_stream_kernel(", "template <int LAY>\n__global__ __launch_bounds__(256) void poisson_stream_kernel(")],
+    # poisson_stream without clearing the call mask (what do the mask stores cost?)
+    "nomask": [("        for (size_t o = w0 + lane; o < w1; o += 64) ((unsigned *)call_mask)[o] = 0u;", "        (void)w1; // variant: mask not cleared")],
+    # poisson_stream without queue pushes
+    "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
+}
+
+
+def build(name):
+    text = open(SRC).read()
+    for old, new in V[name]:
+        assert old in text, (name, old)
+        text = text.replace(old, new)
+    os.makedirs(OUT, exist_ok=True)
+    src = os.path.join(ROOT, "amplisolve_amd", "csrc", f"_variant_{name}.hip")
+    open(src, "w").write(text)
+    try:
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o",
+                        os.path.join(OUT, f"{name}.so"), src], check=True)
+    finally:
+        os.remove(src)
+
+
+if __name__ == "__main__":
+    for n in sys.argv[1:]:
+        build(n)
+        print("built", n)
