@@ -38,3 +38,11 @@ def ctx():
     c = Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _clear_kernel_flags(request):
+    """The session's context keeps AMPLI_FLAG_* bits until somebody reads them: start every test with none raised."""
+    if "ctx" in request.fixturenames:
+        request.getfixturevalue("ctx").flags()
+    yield
