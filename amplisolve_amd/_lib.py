@@ -35,7 +35,7 @@ class Call(C.Structure):
 class Records(C.Structure):
     """mirror of ampli_records: a cohort (or a chunk of a streamed one) on the device, described explicitly"""
     _fields_ = [("recs", vp), ("row_stride", i64), ("ext", vp), ("ext_stride", i64), ("E", i64), ("dup_off", vp),
-                ("ext_pos", vp), ("layout", i32), ("n_samples", i32)]
+                ("ext_pos", vp), ("layout", i32), ("n_samples", i32), ("rd", vp), ("rd_ext", vp)]
 
 
 # every symbol include/amplisolve_hip.h declares: (restype, argtypes)
@@ -140,6 +140,7 @@ HOST_SYMBOLS = {
     "ampli_host_cohort_dup_off": (vp, [vp]),
     "ampli_host_cohort_ext_pos": (vp, [vp]),
     "ampli_host_cohort_line_no": (vp, [vp]),
+    "ampli_host_cohort_irregular": (vp, [vp, C.POINTER(i64)]),
     "ampli_host_cohort_ref_code": (vp, [vp]),
     "ampli_host_cohort_dup_flag": (vp, [vp]),
     "ampli_host_cohort_sample_name": (C.c_char_p, [vp, i32]),

@@ -230,12 +230,14 @@ class Context:
         return acc
 
     def records(self, recs, layout: str, n_samples: int, E: int = 0, row_stride: int = 0, ext=None, ext_stride: int = 0,
-                dup_off=None, ext_pos=None) -> Records:
-        """ampli_records over device tensors (the caller keeps them alive)."""
+                dup_off=None, ext_pos=None, rd=None, rd_ext=None) -> Records:
+        """ampli_records over device tensors (the caller keeps them alive).  rd / rd_ext: int32 [n][P] / [n][E] RD column of
+        lines whose RD is not A+C+G+T (INT32_MIN elsewhere)."""
         r = Records(recs.data_ptr(), row_stride, ext.data_ptr() if ext is not None else None, ext_stride, E,
                     dup_off.data_ptr() if dup_off is not None else None, ext_pos.data_ptr() if ext_pos is not None else None,
-                    self.LAYOUTS[layout], n_samples)
-        r._keep = (recs, ext, dup_off, ext_pos)
+                    self.LAYOUTS[layout], n_samples, rd.data_ptr() if rd is not None else None,
+                    rd_ext.data_ptr() if rd_ext is not None else None)
+        r._keep = (recs, ext, dup_off, ext_pos, rd, rd_ext)
         return r
 
     def error_reduce_records(self, rec: Records, P: int, acc: Acc | None, C_value: float = 0.002, cov: int = 100, first_sample: int = 0,

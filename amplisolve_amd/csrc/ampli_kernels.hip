@@ -388,6 +388,10 @@ struct RecView {
     long long row_stride; // records
     const char *ext;
     long long ext_stride; // records
+    // optional RD column of the lines whose RD differs from A+C+G+T (EE:1178-1181, VC:762-765): rd [n][P], rd_ext [n][E],
+    // AMPLI_ABSENT where the line is regular; NULL when every line of the cohort is
+    const int *rd;
+    const int *rd_ext;
 };
 
 template <int LAY> __host__ __device__ constexpr int rec_bytes_of()
@@ -509,21 +513,23 @@ __device__ __forceinline__ void lane_acc_init(LaneAcc &a)
 }
 
 // One record of one sample at this lane's position.  r0 = {Afw,Cfw,Gfw,Tfw}, r1 = {Ars,Crs,Grs,Trs}.
+// rd_col: the RD column of an irregular line (RD != A+C+G+T), AMPLI_ABSENT otherwise.
 __device__ __forceinline__ void visit_record(LaneAcc &a, const int4 r0, const int4 r1, const int sample,
-                                             const float C, const int cov)
+                                             const float C, const int cov, const int rd_col = AMPLI_ABSENT)
 {
     const bool present = r0.x != AMPLI_ABSENT;
     const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
     const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
     const int FW = fw[0] + fw[1] + fw[2] + fw[3];  // EE:1175
     const int BW = bw[0] + bw[1] + bw[2] + bw[3];  // EE:1176
-    const int RD = FW + BW;                        // ASEQ RD column (host guarantees RD == A+C+G+T)
+    const bool irregular = rd_col != AMPLI_ABSENT; // EE:1178-1181: such a line is used with its own RD (EE:1229-1232)
+    const int RD = irregular ? rd_col : FW + BW;   // the ASEQ RD column
     const bool covok = present && FW >= cov && BW >= cov; // EE:1595, EE:1251 (cov >= 1)
     a.nrec += present ? 1 : 0;                     // Value_Hash.count(key), EE:1659
     if (!__any(covok)) return;                     // wave-uniform: nothing below can change state
 
     // AF <= 0.05 as an integer bound (ampli_math.h); fp form for counts beyond exact floats
-    const bool big = RD >= AMPLI_COUNT_LIMIT;
+    const bool big = irregular || RD >= AMPLI_COUNT_LIMIT; // the literal fp gates: any RD, also a negative or zero one
     const int lim_fw = ampli_af_limit(FW), lim_bw = ampli_af_limit(BW), lim_rd = ampli_af_limit(RD);
     // EE:1597,1599: float(RD_s)*float(C), an fp32 product widened to double
     const double prod_fw = (double)((float)FW * C);
@@ -995,13 +1001,13 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
             // G == 1: s0 / s1 are wave-uniform, the whole wave is here -> the lean Germ_Max path.  Only the 16-byte
             // and 24-byte layouts are VALU-bound enough to profit; with 32-byte records the extra registers cost a wave of occupancy
             if (FAST) visit_fast<G == 1 && LAY != AMPLI_RECORDS_I32>(f, c0, c1, first_sample + s, C, cov);
-            else visit_record(a, c0, c1, first_sample + s, C, cov);
+            else visit_record(a, c0, c1, first_sample + s, C, cov, rv.rd ? rv.rd[(size_t)s * P + p] : AMPLI_ABSENT);
             if (any_dup) { // extras of this position in the same sample, in file order
                 for (unsigned e = e0; e < e1; ++e) {
                     int4 x0, x1;
                     rec_decode<LAY>(rec_load_at<LAY>(rv.ext + ((size_t)s * (size_t)rv.ext_stride + e) * RB), x0, x1);
                     if (FAST) visit_fast<false>(f, x0, x1, first_sample + s, C, cov); // per-lane trip counts: no wave-level shortcuts
-                    else visit_record(a, x0, x1, first_sample + s, C, cov);
+                    else visit_record(a, x0, x1, first_sample + s, C, cov, rv.rd_ext ? rv.rd_ext[(size_t)s * E + e] : AMPLI_ABSENT);
                 }
                 if (FAST && G == 1 && LAY != AMPLI_RECORDS_I32) { // the extras may have given lanes their first record
 #pragma unroll
@@ -1360,7 +1366,9 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
         const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
         const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
         const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
-        const int RD = FW + BW;
+        const int *rdp = r < P ? rv.rd : rv.rd_ext;   // the RD column of lines where it is not A+C+G+T (VC:762-765)
+        const int rdc = rdp ? rdp[r < P ? (size_t)t * P + r : (size_t)t * E + (r - P)] : AMPLI_ABSENT;
+        const int RD = rdc != AMPLI_ABSENT ? rdc : FW + BW;
         const bool covok = FW >= cov && BW >= cov;    // VC:898
         unsigned mask = 0;
         if (qd) {
@@ -1470,7 +1478,7 @@ __device__ __forceinline__ void pc_flush(const PcItem *__restrict__ st, const in
     if (fit < count && lane == 0) atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
 }
 
-template <int LAY>
+template <int LAY, bool IRR>
 __global__ __launch_bounds__(256, 8) void poisson_stream_kernel(
     const RecView rv, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const int rows_per_wave, const unsigned gy, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
@@ -1534,12 +1542,17 @@ __global__ __launch_bounds__(256, 8) void poisson_stream_kernel(
         const int bw[4] = {r1v.x, r1v.y, r1v.z, r1v.w};
         const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
         const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
-        const int RD = FW + BW;
+        int RD = FW + BW;
+        if (IRR) { // cohorts with lines whose RD column is not A+C+G+T (VC:762-765): the column decides (VC:895, VC:814)
+            const int *rdp = r < P ? rv.rd : rv.rd_ext;
+            const int rdc = rdp ? rdp[r < P ? (size_t)(t0 + dt) * P + r : (size_t)(t0 + dt) * E + (r - P)] : AMPLI_ABSENT;
+            if (rdc != AMPLI_ABSENT) RD = rdc;
+        }
         const int d_fw = RD - BW, d_bw = BW;          // VC:895-896
         const bool live = valid && r0v.x != AMPLI_ABSENT && ref <= 3 && FW >= cov && BW >= cov; // VC:898, VC:3290
         // conservative fp32 bound (ampli_prefilter_skip_f32, hoisted); depths or counts >= 2^24 are not exact
         // floats: never skip those
-        const bool exact = (unsigned)RD < (unsigned)AMPLI_COUNT_LIMIT && FW >= 0 && BW >= 0;
+        const bool exact = (unsigned)RD < (unsigned)AMPLI_COUNT_LIMIT && FW >= 0 && BW >= 0 && d_fw >= 0;
         const float c_fw = (float)d_fw * 0.999999f, c_bw = (float)d_bw * 0.999999f;
         unsigned pushmask = 0;
 #pragma unroll
@@ -1786,6 +1799,7 @@ static DevCohort dense_cohort(const ampli_ctx *ctx, const void *d_recs, int64_t 
     c.rv.row_stride = P + E;
     c.rv.ext = (const char *)d_recs + (size_t)P * rec_bytes_rt(c.layout);
     c.rv.ext_stride = P + E;
+    c.rv.rd = nullptr; c.rv.rd_ext = nullptr;
     c.n = n; c.E = E; c.dup_off = dup_off; c.ext_pos = ext_pos;
     return c;
 }
@@ -1799,6 +1813,8 @@ static int cohort_from_records(ampli_ctx *ctx, const ampli_records *r, int64_t P
     c.n = r->n_samples;
     c.E = r->E;
     c.dup_off = r->dup_off; c.ext_pos = r->ext_pos;
+    c.rv.rd = r->rd;
+    c.rv.rd_ext = r->rd_ext;
     c.rv.base = (const char *)r->recs;
     c.rv.row_stride = r->row_stride > 0 ? r->row_stride : (r->ext ? P : P + r->E);
     if (r->ext) {
@@ -1852,7 +1868,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         if (splits < 1) splits = 1;
     }
     if (splits > S) splits = S;
-    const bool fast = !ctx->reduce_general;
+    const bool fast = !ctx->reduce_general && !co.rv.rd && !co.rv.rd_ext; // lines with their own RD column: the literal kernel
     if (fast) { // int32 partial sums: a lane takes at most FAST_MAX_CHUNK samples
         const int need = (S + RED_WAVES * G * FAST_MAX_CHUNK - 1) / (RED_WAVES * G * FAST_MAX_CHUNK);
         if (splits < need) splits = need;
@@ -2245,13 +2261,16 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
         else
             ctx->queue_parity ^= 1;
         dim3 qgrid((unsigned)(tiles8 * gy));
-#define AMPLI_LAUNCH_STREAM(LV)                                                                                                  \
-    hipLaunchKernelGGL(poisson_stream_kernel<LV>, qgrid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                          \
-                       (long long)E, d_ext_pos, (int)T, rpw, (unsigned)gy, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, \
+        const bool irr = co.rv.rd || co.rv.rd_ext;
+#define AMPLI_LAUNCH_STREAM_I(LV, IV)                                                                                            \
+    hipLaunchKernelGGL((poisson_stream_kernel<LV, IV>), qgrid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                    \
+                       (long long)E, d_ext_pos, (int)T, rpw, (unsigned)gy, d_thr, thr_L, thr_bb, d_ref_code, (int)cov,            \
                        (PcItem *)ctx->queue, per, qn, d_call_mask, ctx->d_flags, d_n_calls)
+#define AMPLI_LAUNCH_STREAM(LV) do { if (irr) AMPLI_LAUNCH_STREAM_I(LV, true); else AMPLI_LAUNCH_STREAM_I(LV, false); } while (0)
         if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
         else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
         else AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_I32);
+#undef AMPLI_LAUNCH_STREAM_I
 #undef AMPLI_LAUNCH_STREAM
         int rc = check_launch(ctx, "poisson_stream_kernel");
         if (rc) return rc;

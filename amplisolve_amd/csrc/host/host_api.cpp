@@ -68,6 +68,11 @@ extern "C" const int32_t *ampli_host_cohort_recs(const ampli_host_cohort *h) { r
 extern "C" const uint32_t *ampli_host_cohort_dup_off(const ampli_host_cohort *h) { return h->cohort.dup_off.data(); }
 extern "C" const uint32_t *ampli_host_cohort_ext_pos(const ampli_host_cohort *h) { return h->cohort.ext_pos.data(); }
 extern "C" const int32_t *ampli_host_cohort_line_no(const ampli_host_cohort *h) { return h->cohort.line_no.empty() ? nullptr : h->cohort.line_no.data(); }
+extern "C" const uint32_t *ampli_host_cohort_irregular(const ampli_host_cohort *h, int64_t *n)
+{
+    if (n) *n = (int64_t)h->cohort.irregular.size();
+    return h->cohort.irregular.empty() ? nullptr : (const uint32_t *)h->cohort.irregular.data();
+}
 extern "C" const uint8_t *ampli_host_cohort_ref_code(const ampli_host_cohort *h) { return h->panel.ref_code.data(); }
 extern "C" const uint8_t *ampli_host_cohort_dup_flag(const ampli_host_cohort *h) { return h->panel.dup.data(); }
 extern "C" const char *ampli_host_cohort_sample_name(const ampli_host_cohort *h, int32_t s)

@@ -103,7 +103,7 @@ struct DevBuf {
 };
 
 struct DevSlot {
-    DevBuf prim, ext, aux, mask;
+    DevBuf prim, ext, aux, mask, rd, rd_ext;
 };
 
 size_t chunk_bytes_setting()
@@ -139,6 +139,24 @@ ampli_records upload_chunk(Dev &dev, DevSlot &ds, const Chunk &c, bool for_calli
         dev.check(dev.api->copy_h2d(dev.ctx, d_aux, aux.data(), aux.size() * sizeof(uint32_t)), "ampli_copy_h2d");
         if (for_calling) r.ext_pos = (const uint32_t *)d_aux;
         else r.dup_off = (const uint32_t *)d_aux;
+    }
+    if (!c.irregular.empty()) {
+        // lines whose RD column is not A+C+G+T (EE:1178-1181, VC:762-765): the column travels as an int32 plane beside the
+        // records (AMPLI_ABSENT = regular line) and the kernels use it where the reference does (EE:1229, VC:814, VC:895)
+        std::vector<int32_t> rd((size_t)c.n * c.P, AMPLI_ABSENT), rde((size_t)c.n * c.E, AMPLI_ABSENT);
+        for (const Irregular &x : c.irregular) {
+            if ((int64_t)x.record < c.P) rd[(size_t)x.sample * c.P + x.record] = x.rd;
+            else rde[(size_t)x.sample * c.E + (x.record - c.P)] = x.rd;
+        }
+        void *d_rd = ds.rd.ensure(dev, rd.size() * sizeof(int32_t));
+        dev.check(dev.api->copy_h2d(dev.ctx, d_rd, rd.data(), rd.size() * sizeof(int32_t)), "ampli_copy_h2d");
+        r.rd = (const int32_t *)d_rd;
+        if (c.E > 0) {
+            void *d_rde = ds.rd_ext.ensure(dev, rde.size() * sizeof(int32_t));
+            dev.check(dev.api->copy_h2d(dev.ctx, d_rde, rde.data(), rde.size() * sizeof(int32_t)), "ampli_copy_h2d");
+            r.rd_ext = (const int32_t *)d_rde;
+        }
+        dev.sync(); // the host vectors go out of scope
     }
     return r;
 }

@@ -48,9 +48,21 @@ class HostCohort:
         self.ext_pos = arr(lib.ampli_host_cohort_ext_pos(h), (self.E,), np.uint32)
         ln = lib.ampli_host_cohort_line_no(h)
         self.line_no = arr(ln, (self.S, R), np.int32) if ln else None
+        n_irr = C.c_int64()
+        ip = lib.ampli_host_cohort_irregular(h, C.byref(n_irr))
+        self.irregular = arr(ip, (n_irr.value, 4), np.uint32).astype(np.int64) if n_irr.value else np.zeros((0, 4), np.int64)
         self.ref_code = arr(lib.ampli_host_cohort_ref_code(h), (self.P,), np.uint8)
         self.dup_flag = arr(lib.ampli_host_cohort_dup_flag(h), (self.P,), np.uint8)
         self.names = [lib.ampli_host_cohort_sample_name(h, s).decode() for s in range(self.S)]
+
+    def rd_plane(self):
+        """int32 [S][P+E]: the RD column of the lines where it is not A+C+G+T, INT32_MIN elsewhere (None: no such line)"""
+        if not len(self.irregular):
+            return None
+        rd = np.full((self.S, self.P + self.E), np.iinfo(np.int32).min, np.int32)
+        for s, r, _, v in self.irregular:
+            rd[s, r] = np.int32(np.uint32(v).astype(np.int32)) if v > 0x7FFFFFFF else v
+        return rd
 
     def stats(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()

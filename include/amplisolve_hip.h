@@ -176,6 +176,7 @@ int ampli_error_estimate(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64
  *   ext_stride  0 = E
  *   E, dup_off [P+1] (error_reduce), ext_pos [E] (poisson_call): as in the classic entry points; a chunk may carry
  *               its own E / dup_off / ext_pos (slots for the multiplicities seen in ITS files)
+ *   rd, rd_ext  optional RD column of irregular lines (below)
  */
 typedef struct ampli_records {
     const void *recs;
@@ -187,6 +188,13 @@ typedef struct ampli_records {
     const uint32_t *ext_pos;
     int32_t layout;
     int32_t n_samples;
+    /* optional: the RD column of the lines whose RD differs from A+C+G+T (EE:1178-1181, VC:762-765).  The reference
+     * goes on to use the column: as the denominator of the Germ_Max AF (EE:1229-1232) and, in the caller, in AF = X/RD
+     * and in the forward depth RD - RD_reverse of the Poisson test (VC:814-817, VC:895).  DEVICE int32 rd [n_samples][P],
+     * rd_ext [n_samples][E], AMPLI_ABSENT where the line is regular; NULL = every line of the cohort is regular (the
+     * fast kernels; a cohort with an RD plane goes through the literal reduce kernel). */
+    const int32_t *rd;
+    const int32_t *rd_ext;
 } ampli_records;
 
 /*

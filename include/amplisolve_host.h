@@ -64,6 +64,8 @@ const int32_t *ampli_host_cohort_recs(const ampli_host_cohort *h);    /* [S][P+E
 const uint32_t *ampli_host_cohort_dup_off(const ampli_host_cohort *h);/* [P+1] */
 const uint32_t *ampli_host_cohort_ext_pos(const ampli_host_cohort *h);/* [E] */
 const int32_t *ampli_host_cohort_line_no(const ampli_host_cohort *h); /* [S][P+E] or NULL */
+/* lines whose RD column is not A+C+G+T: *n entries of four 32-bit words {sample, record slot, occurrence, RD column} */
+const uint32_t *ampli_host_cohort_irregular(const ampli_host_cohort *h, int64_t *n);
 const uint8_t *ampli_host_cohort_ref_code(const ampli_host_cohort *h);/* [P] */
 const uint8_t *ampli_host_cohort_dup_flag(const ampli_host_cohort *h);/* [P] */
 const char *ampli_host_cohort_sample_name(const ampli_host_cohort *h, int32_t s);

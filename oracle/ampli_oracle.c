@@ -141,7 +141,9 @@ void oracle_af_gate_batch(const int32_t *x, const int32_t *d, int64_t n, uint8_t
     for (int64_t i = 0; i < n; ++i) out[i] = (uint8_t)oracle_af_gate(x[i], d[i]);
 }
 
-static inline void visit_record(const int32_t *r, int32_t sample_index, float C, int32_t cov,
+/* rd_col: the RD column of the line, or ORACLE_ABSENT for "equal to A+C+G+T" (the usual case; a line where it differs
+ * prints EE:1178-1181's message and is then used with its own RD: EE:1229-1232 divide by it) */
+static inline void visit_record(const int32_t *r, int32_t rd_col, int32_t sample_index, float C, int32_t cov,
                                 int64_t p, int64_t P, double *snt, double *srd_d, int32_t *cnt,
                                 int32_t *nrec, int32_t *gm_n, int32_t *gm_first,
                                 float *gm_first_af, float *gm_rest)
@@ -150,7 +152,7 @@ static inline void visit_record(const int32_t *r, int32_t sample_index, float C,
     /* EE:1175-1176 */
     int FW = r[0] + r[1] + r[2] + r[3];
     int BW = r[4] + r[5] + r[6] + r[7];
-    int RD = FW + BW; /* the ASEQ RD column; the host guarantees RD == A+C+G+T */
+    int RD = rd_col == ORACLE_ABSENT ? FW + BW : rd_col; /* the ASEQ RD column (EE:1149) */
     nrec[p] += 1;     /* Value_Hash.count(key), EE:1659 */
     for (int nt = 0; nt < 4; ++nt) {
         int base_fw = r[nt], base_bw = r[4 + nt];
@@ -187,7 +189,19 @@ void oracle_error_reduce(const int32_t *recs, int64_t P, int64_t E, const uint32
                          int32_t *gm_first, float *gm_first_af, float *gm_rest,
                          int32_t *order_sensitive)
 {
+    oracle_error_reduce_rd(recs, NULL, P, E, dup_off, S, first_sample, C, cov, snt, srd, cnt, nrec, gm_n, gm_first,
+                           gm_first_af, gm_rest, order_sensitive);
+}
+
+/* the same with the RD column of every record: rdcol [S][P+E], ORACLE_ABSENT where it equals A+C+G+T; NULL = all regular */
+void oracle_error_reduce_rd(const int32_t *recs, const int32_t *rdcol, int64_t P, int64_t E, const uint32_t *dup_off,
+                            int32_t S, int32_t first_sample, float C, int32_t cov, double *snt,
+                            int64_t *srd, int32_t *cnt, int32_t *nrec, int32_t *gm_n,
+                            int32_t *gm_first, float *gm_first_af, float *gm_rest,
+                            int32_t *order_sensitive)
+{
     const int64_t R = P + E;
+#define RDC(s_, r_) (rdcol ? rdcol[(size_t)(s_) * R + (r_)] : ORACLE_ABSENT)
     double *srd_d = (double *)calloc((size_t)(8 * P), sizeof(double));
     for (int64_t i = 0; i < 8 * P; ++i) snt[i] = 0.0;
     for (int64_t i = 0; i < 4 * P; ++i) {
@@ -203,11 +217,11 @@ void oracle_error_reduce(const int32_t *recs, int64_t P, int64_t E, const uint32
     for (int64_t p = 0; p < P; ++p) {
         for (int32_t s = 0; s < S; ++s) {
             const int32_t *base = recs + (size_t)s * R * 8;
-            visit_record(base + p * 8, first_sample + s, C, cov, p, P, snt, srd_d, cnt, nrec, gm_n,
+            visit_record(base + p * 8, RDC(s, p), first_sample + s, C, cov, p, P, snt, srd_d, cnt, nrec, gm_n,
                          gm_first, gm_first_af, gm_rest);
             if (dup_off)
                 for (uint32_t e = dup_off[p]; e < dup_off[p + 1]; ++e)
-                    visit_record(base + (P + e) * 8, first_sample + s, C, cov, p, P, snt, srd_d,
+                    visit_record(base + (P + e) * 8, RDC(s, P + e), first_sample + s, C, cov, p, P, snt, srd_d,
                                  cnt, nrec, gm_n, gm_first, gm_first_af, gm_rest);
         }
     }
@@ -231,15 +245,16 @@ void oracle_error_reduce(const int32_t *recs, int64_t P, int64_t E, const uint32
                 const int32_t *base = recs + (size_t)s * R * 8;
                 if (dup_off)
                     for (uint32_t e = dup_off[p + 1]; e > dup_off[p]; --e)
-                        visit_record(base + (P + e - 1) * 8, s, C, cov, p, P, snt2, srd2, cnt2,
+                        visit_record(base + (P + e - 1) * 8, RDC(s, P + e - 1), s, C, cov, p, P, snt2, srd2, cnt2,
                                      nrec2, g1, g2, g3, g4);
-                visit_record(base + p * 8, s, C, cov, p, P, snt2, srd2, cnt2, nrec2, g1, g2, g3, g4);
+                visit_record(base + p * 8, RDC(s, p), s, C, cov, p, P, snt2, srd2, cnt2, nrec2, g1, g2, g3, g4);
             }
         }
         if (memcmp(snt, snt2, (size_t)(8 * P) * sizeof(double)) != 0) *order_sensitive = 1;
         free(snt2); free(srd2); free(cnt2); free(nrec2); free(g1); free(g2); free(g3); free(g4);
     }
     free(srd_d);
+#undef RDC
 }
 
 /* Ordered combine of two partial tables, L covering earlier samples than R.
@@ -352,6 +367,14 @@ void oracle_poisson_call(const int32_t *trecs, int64_t P, int64_t E, const uint3
                          int32_t T, const float *thr, const uint8_t *ref_code, int32_t cov,
                          uint8_t *call_mask, double *q, float *af)
 {
+    oracle_poisson_call_rd(trecs, NULL, P, E, ext_pos, T, thr, ref_code, cov, call_mask, q, af);
+}
+
+/* the same with the RD column of every record (VC:752): rdcol [T][P+E], ORACLE_ABSENT where it equals A+C+G+T */
+void oracle_poisson_call_rd(const int32_t *trecs, const int32_t *rdcol, int64_t P, int64_t E, const uint32_t *ext_pos,
+                            int32_t T, const float *thr, const uint8_t *ref_code, int32_t cov,
+                            uint8_t *call_mask, double *q, float *af)
+{
     const int64_t R = P + E;
     for (int32_t t = 0; t < T; ++t) {
         for (int64_t r = 0; r < R; ++r) {
@@ -365,7 +388,7 @@ void oracle_poisson_call(const int32_t *trecs, int64_t P, int64_t E, const uint3
             /* VC:760-761 */
             int FW = c[0] + c[1] + c[2] + c[3];
             int BW = c[4] + c[5] + c[6] + c[7];
-            int RD = FW + BW;
+            int RD = (rdcol && rdcol[(size_t)t * R + r] != ORACLE_ABSENT) ? rdcol[(size_t)t * R + r] : FW + BW; /* the RD column, VC:752 */
             int RD_reverse = BW; /* VC:819 */
             if (af) {
                 for (int nt = 0; nt < 4; ++nt) {

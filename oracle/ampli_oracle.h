@@ -61,6 +61,12 @@ void oracle_error_reduce(const int32_t *recs, int64_t P, int64_t E, const uint32
                          int32_t *gm_n /*[4][P]*/, int32_t *gm_first /*[4][P]*/,
                          float *gm_first_af /*[4][P]*/, float *gm_rest /*[4][P]*/,
                          int32_t *order_sensitive /* out: 1 if reverse-order double sums differ */);
+/* the same with the RD column of every record (EE:1149): rdcol [S][P+E], INT32_MIN where it equals A+C+G+T; NULL = all
+ * regular.  A line whose RD differs is used with its own RD in the Germ_Max AF (EE:1229-1232). */
+void oracle_error_reduce_rd(const int32_t *recs, const int32_t *rdcol, int64_t P, int64_t E, const uint32_t *dup_off,
+                            int32_t S, int32_t first_sample, float C, int32_t cov, double *snt, int64_t *srd, int32_t *cnt,
+                            int32_t *nrec, int32_t *gm_n, int32_t *gm_first, float *gm_first_af, float *gm_rest,
+                            int32_t *order_sensitive);
 
 /* ordered merge of two partial tables (L = earlier samples); result into L */
 void oracle_acc_merge(int64_t P, double *snt, int64_t *srd, int32_t *cnt, int32_t *nrec,
@@ -89,6 +95,10 @@ void oracle_poisson_call(const int32_t *trecs, int64_t P, int64_t E, const uint3
                          int32_t cov, uint8_t *call_mask /*[T][R]*/,
                          double *q /*optional [T][R][4][2], -1 = not evaluated*/,
                          float *af /*optional [T][R][4][3] = AF, AF_fw, AF_bw*/);
+/* the same with the RD column of every record (VC:752): forward depth RD - RD_reverse (VC:895), AF = X / RD (VC:814-817) */
+void oracle_poisson_call_rd(const int32_t *trecs, const int32_t *rdcol, int64_t P, int64_t E, const uint32_t *ext_pos,
+                            int32_t T, const float *thr, const uint8_t *ref_code, int32_t cov, uint8_t *call_mask, double *q,
+                            float *af);
 
 /* ---- integer AF-gate equivalence helper used by the product kernels ---- */
 /* 1 iff (double)((float)x/(float)d) <= 0.05, evaluated exactly like EE:1592-1595 */

@@ -63,17 +63,21 @@ def score_batch(k, rd, err):
     return q, p
 
 
-def error_reduce(recs, P, C_value=0.002, cov=100, E=0, dup_off=None, first_sample=0):
+def error_reduce(recs, P, C_value=0.002, cov=100, E=0, dup_off=None, first_sample=0, rd=None):
+    """rd: optional int32 [S][P+E] RD column, INT32_MIN where the line's RD equals A+C+G+T"""
     recs = np.ascontiguousarray(recs, np.int32)
     S = recs.shape[0]
     assert recs.size == S * (P + E) * 8
+    if rd is not None:
+        rd = np.ascontiguousarray(rd, np.int32)
+        assert rd.size == S * (P + E)
     out = dict(snt=np.empty((2, 4, P), np.float64), srd=np.empty((2, 4, P), np.int64), cnt=np.empty((4, P), np.int32),
                nrec=np.empty((P,), np.int32), gm_n=np.empty((4, P), np.int32), gm_first=np.empty((4, P), np.int32),
                gm_first_af=np.empty((4, P), np.float32), gm_rest=np.empty((4, P), np.float32))
     flag = C.c_int32(0)
     if dup_off is not None:
         dup_off = np.ascontiguousarray(dup_off, np.uint32)
-    lib().oracle_error_reduce(_p(recs), C.c_int64(P), C.c_int64(E), _p(dup_off), C.c_int32(S), C.c_int32(first_sample),
+    lib().oracle_error_reduce_rd(_p(recs), _p(rd), C.c_int64(P), C.c_int64(E), _p(dup_off), C.c_int32(S), C.c_int32(first_sample),
                               C.c_float(C_value), C.c_int32(cov), _p(out["snt"]), _p(out["srd"]), _p(out["cnt"]),
                               _p(out["nrec"]), _p(out["gm_n"]), _p(out["gm_first"]), _p(out["gm_first_af"]),
                               _p(out["gm_rest"]), C.byref(flag))
@@ -102,11 +106,15 @@ def error_finalize(acc):
     return out
 
 
-def poisson_call(trecs, P, thr, ref_code, cov=100, E=0, ext_pos=None, dense=True):
+def poisson_call(trecs, P, thr, ref_code, cov=100, E=0, ext_pos=None, dense=True, rd=None):
+    """rd: optional int32 [T][P+E] RD column, INT32_MIN where the line's RD equals A+C+G+T"""
     trecs = np.ascontiguousarray(trecs, np.int32)
     T = trecs.shape[0]
     R = P + E
     assert trecs.size == T * R * 8
+    if rd is not None:
+        rd = np.ascontiguousarray(rd, np.int32)
+        assert rd.size == T * R
     thr = np.ascontiguousarray(thr, np.float32)
     ref_code = np.ascontiguousarray(ref_code, np.uint8)
     mask = np.empty((T, R), np.uint8)
@@ -114,7 +122,7 @@ def poisson_call(trecs, P, thr, ref_code, cov=100, E=0, ext_pos=None, dense=True
     af = np.empty((T, R, 4, 3), np.float32) if dense else None
     if ext_pos is not None:
         ext_pos = np.ascontiguousarray(ext_pos, np.uint32)
-    lib().oracle_poisson_call(_p(trecs), C.c_int64(P), C.c_int64(E), _p(ext_pos), C.c_int32(T), _p(thr), _p(ref_code),
+    lib().oracle_poisson_call_rd(_p(trecs), _p(rd), C.c_int64(P), C.c_int64(E), _p(ext_pos), C.c_int32(T), _p(thr), _p(ref_code),
                               C.c_int32(cov), _p(mask), _p(q), _p(af))
     return dict(call_mask=mask, q=q, af=af)
 

@@ -155,3 +155,58 @@ def test_poisson_launch_shape_never_changes_a_result(ctx, rows, blocks):
         for st, name in enumerate(("q_fw", "q_bw")):
             e = qo[c["sample"], c["record"], c["alt"], st]
             assert abs(c[name] - e) <= 1e-6 * max(1.0, abs(e))
+
+
+@pytest.mark.parametrize("layout", ["i32", "u24"])
+def test_lines_with_their_own_rd_column(ctx, layout):
+    """RD != A+C+G+T (EE:1178-1181, VC:762-765): the column travels as a plane beside the records and decides where the
+    reference lets it -- Germ_Max AF = X / RD (EE:1229-1232), AF = X / RD and forward depth RD - RD_reverse in the caller
+    (VC:814-817, VC:895) -- incl. RD = 0, RD below the reverse depth, RD far above the sum."""
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+
+    rng = np.random.default_rng(23)
+    P, S = 600, 21
+    recs, E, dup_off = _panel_with_extras(P, S, rng)
+    R = P + E
+    rd = np.full((S, R), ABSENT, np.int32)
+    pick = rng.random((S, R)) < 0.2
+    tot = np.where(recs[:, :, 0] == ABSENT, 0, recs.sum(-1))
+    choice = rng.integers(0, 7, (S, R))
+    alt = np.select([choice == 0, choice == 1, choice == 2, choice == 3, choice == 4, choice == 5], [tot * 2, tot + 37, tot // 2, tot // 3, 0 * tot, 7 + 0 * tot], tot * 40)
+    rd[pick] = alt[pick].astype(np.int32)
+    ref = orc.error_reduce(recs, P, 0.002, 100, E=E, dup_off=dup_off, rd=rd)
+    assert not np.array_equal(ref["gm_n"], orc.error_reduce(recs, P, 0.002, 100, E=E, dup_off=dup_off)["gm_n"])
+    prim = np.ascontiguousarray(recs[:, :P])
+    ext = np.ascontiguousarray(recs[:, P:])
+    rec = ctx.records(_pack(ctx, prim, layout), layout, S, E=E, ext=_pack(ctx, ext, layout), dup_off=_t(dup_off),
+                      rd=_t(np.ascontiguousarray(rd[:, :P])), rd_ext=_t(np.ascontiguousarray(rd[:, P:])))
+    acc = ctx.new_acc(P)
+    fin = ctx.error_reduce_records(rec, P, acc, 0.002, 100, finalize=True)
+    assert ctx.flags() == 0
+    assert_acc_equal(acc, ref)
+    assert_final_equal(fin, orc.error_finalize(ref))
+    # the calling half on the same kind of cohort
+    T = 9
+    trecs = edge_case_recs(R, T, rng)
+    trecs[:, ::5, :] = np.array([30, 0, 0, 400, 25, 0, 0, 380], np.int32)
+    trd = np.full((T, R), ABSENT, np.int32)
+    tp = rng.random((T, R)) < 0.3
+    ttot = np.where(trecs[:, :, 0] == ABSENT, 0, trecs.sum(-1))
+    tch = rng.integers(0, 6, (T, R))
+    talt = np.select([tch == 0, tch == 1, tch == 2, tch == 3, tch == 4], [ttot * 2, ttot + 11, ttot // 2, 0 * ttot, trecs[:, :, 4:].sum(-1) - 3], ttot * 9)
+    trd[tp] = talt[tp].astype(np.int32)
+    thr = rng.choice(np.array([0.002, 0.01, 0.0, -1.0, 0.000731, 0.05], np.float32), size=(2, 4, P)).astype(np.float32)
+    ref_code = rng.integers(0, 4, P).astype(np.uint8)
+    ext_pos = np.repeat(np.arange(P), np.diff(dup_off.astype(np.int64))).astype(np.uint32)
+    exp = orc.poisson_call(trecs, P, thr, ref_code, 100, E=E, ext_pos=ext_pos, rd=trd)
+    exp0 = orc.poisson_call(trecs, P, thr, ref_code, 100, E=E, ext_pos=ext_pos)
+    assert exp["call_mask"].any() and not np.array_equal(exp["call_mask"], exp0["call_mask"])
+    trec = ctx.records(_pack(ctx, np.ascontiguousarray(trecs[:, :P]), layout), layout, T, E=E, ext=_pack(ctx, np.ascontiguousarray(trecs[:, P:]), layout),
+                       ext_pos=_t(ext_pos), rd=_t(np.ascontiguousarray(trd[:, :P])), rd_ext=_t(np.ascontiguousarray(trd[:, P:])))
+    for mode in (POISSON_FULL, POISSON_PREFILTER):
+        res = ctx.poisson_call_records(trec, P, _t(thr), _t(ref_code), 100, mode=mode, capacity=32 * 3 * R * T)  # every call could land in one segment
+        assert np.array_equal(res["call_mask"].cpu().numpy(), exp["call_mask"])
+        for c in ctx.read_calls(res):
+            r = trecs[c["sample"], c["record"]]
+            want_rd = trd[c["sample"], c["record"]] if trd[c["sample"], c["record"]] != ABSENT else r.sum()
+            assert c["rd"] == want_rd and np.float32(c["af"]) == exp["af"][c["sample"], c["record"], c["alt"], 0]

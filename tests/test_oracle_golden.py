@@ -6,6 +6,7 @@ Fixtures under tests/golden/ were produced by tests/golden/make_golden.py from t
 import gzip
 import hashlib
 import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -137,3 +138,23 @@ def test_scorer_bitwise_vs_reference_random():
                       want.ctypes.data_as(C.c_void_p))
     got, _ = orc.score_batch(k, rd, err)
     assert np.array_equal(got.view(np.int64), want.view(np.int64))
+
+
+def test_irregular_lines_oracle_reproduces_the_reference_table():
+    """Lines whose RD column is not A+C+G+T (a quarter of the lines of this fixture, in ways that move the AF <= 0.05 gate
+    of Germ_Max both ways): the oracle, fed the RD column beside the records, writes the reference's table byte for byte
+    (tests/golden/irregular, generated by make_golden_irregular.py from the compiled reference)."""
+    d = os.path.join(G, "irregular")
+    for tag, C_value, cov in (("0.0020_cov100", 0.002, 100), ("0.0100_cov1", 0.01, 1)):
+        co = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
+        assert co.names == open(f"{d}/expected_visit_order.txt").read().split()
+        rd = co.rd_plane()
+        assert rd is not None and (rd != np.iinfo(np.int32).min).sum() == co.stats()["irregular"] == 383
+        acc = orc.error_reduce(co.recs, co.P, C_value, cov, E=co.E, dup_off=co.dup_off, rd=rd)
+        fin = orc.error_finalize(acc)
+        out = os.path.join(tempfile.mkdtemp(), "t.txt")
+        co.write_error_table(fin["rate"], fin["code"], fin["germ_val"].astype(np.float32), fin["germ_present"], out)
+        assert open(out).read() == open(f"{d}/expected_positionSpecificNoise_{tag}.txt").read()
+        # and without the column the table is NOT the reference's: the fixture really exercises it
+        acc0 = orc.error_reduce(co.recs, co.P, C_value, cov, E=co.E, dup_off=co.dup_off)
+        assert not np.array_equal(acc0["gm_n"], acc["gm_n"])
