@@ -29,7 +29,7 @@ class Call(C.Structure):
     """mirror of ampli_call"""
     _fields_ = [("sample", i32), ("record", i32), ("alt", i32), ("rd", i32), ("q_fw", C.c_double),
                 ("q_bw", C.c_double), ("af", f32), ("af_fw", f32), ("af_bw", f32), ("k_fw", i32), ("k_bw", i32),
-                ("fw", i32), ("bw", i32), ("pad", i32)]
+                ("fw", i32), ("bw", i32), ("flags", i32)]
 
 
 class Records(C.Structure):
@@ -155,6 +155,7 @@ HOST_SYMBOLS = {
     "ampli_host_run_error_estimation_sharded": (C.c_int, [C.c_char_p] * 8 + [C.POINTER(HostShard)]),
     "ampli_host_run_variant_calling_sharded": (C.c_int, [C.c_char_p] * 5 + [C.POINTER(HostShard)]),
     "ampli_host_fisher": (C.c_double, [C.c_int] * 4),
+    "ampli_host_guard_score": (C.c_double, [i32, i32, f32, C.POINTER(i32), C.POINTER(i32)]),
 }
 
 _hip = None

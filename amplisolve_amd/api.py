@@ -421,7 +421,7 @@ class Context:
         raw = b"".join(res["calls_buf"][k * per * sz: (k * per + int(counts[k])) * sz].cpu().numpy().tobytes() for k in range(CALL_SHARDS))
         dt = np.dtype([("sample", "<i4"), ("record", "<i4"), ("alt", "<i4"), ("rd", "<i4"), ("q_fw", "<f8"),
                        ("q_bw", "<f8"), ("af", "<f4"), ("af_fw", "<f4"), ("af_bw", "<f4"), ("k_fw", "<i4"), ("k_bw", "<i4"),
-                       ("fw", "<i4"), ("bw", "<i4"), ("pad", "<i4")])
+                       ("fw", "<i4"), ("bw", "<i4"), ("flags", "<i4")])
         assert dt.itemsize == sz
         a = np.frombuffer(raw, dtype=dt)
         a = a[np.lexsort((a["alt"], a["record"], a["sample"]))]

@@ -1322,14 +1322,14 @@ __device__ __forceinline__ float thr_at(const float *__restrict__ thr, const lon
 
 // the reported VAFs and the evidence of one emitted call (VC:772-817)
 __device__ __forceinline__ void call_fill(ampli_call &c, const int sample, const int record, const int alt, const int rd, const double q_fw,
-                                          const double q_bw, const int k_fw, const int k_bw, const int FW, const int BW)
+                                          const double q_bw, const int k_fw, const int k_bw, const int FW, const int BW, const int flags = 0)
 {
     c.sample = sample; c.record = record; c.alt = alt; c.rd = rd;
     c.q_fw = q_fw; c.q_bw = q_bw;
     c.af = (float)(k_fw + k_bw) / (float)rd;               // VC:814-817
     c.af_fw = FW == 0 ? 0.0f : (float)k_fw / (float)FW;    // VC:785-790
     c.af_bw = BW == 0 ? 0.0f : (float)k_bw / (float)BW;    // VC:805-810
-    c.k_fw = k_fw; c.k_bw = k_bw; c.fw = FW; c.bw = BW; c.pad = 0;
+    c.k_fw = k_fw; c.k_bw = k_bw; c.fw = FW; c.bw = BW; c.flags = flags;
 }
 
 template <int MODE, int LAY>
@@ -1394,22 +1394,23 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
                     if (!covok) continue;
                     if (ampli_prefilter_nocall(k_fw, d_fw, th[0][nt]) || ampli_prefilter_nocall(k_bw, d_bw, th[1][nt])) continue;
                     q_fw = ampli_poisson_score(k_fw, d_fw, th[0][nt]);
-                    if (!(q_fw >= 5)) continue;
+                    if (!(q_fw >= 5.0 - AMPLI_CALL_GATE_EPS)) continue;
                     q_bw = ampli_poisson_score(k_bw, d_bw, th[1][nt]);
                 } else {
                     q_fw = ampli_poisson_score(k_fw, d_fw, th[0][nt]);
                     q_bw = ampli_poisson_score(k_bw, d_bw, th[1][nt]);
                     if (qd) { qd[o * 8 + nt * 2 + 0] = q_fw; qd[o * 8 + nt * 2 + 1] = q_bw; }
                 }
-                if (covok && q_fw >= 5 && q_bw >= 5) { // VC:898
-                    mask |= 1u << nt;
-                    if (n_calls) {
-                        const long long idx = call_slot(n_calls, capacity);
-                        if (calls && idx >= 0) {
-                            ampli_call c;
-                            call_fill(c, t, (int)r, nt, RD, q_fw, q_bw, k_fw, k_bw, FW, BW);
-                            calls[idx] = c;
-                        }
+                const bool is_call = covok && q_fw >= 5 && q_bw >= 5; // VC:898
+                const double lo = 5.0 - AMPLI_CALL_GATE_EPS, hi = 5.0 + AMPLI_CALL_GATE_EPS;
+                const bool near_gate = covok && q_fw >= lo && q_bw >= lo && (q_fw < hi || q_bw < hi); // AMPLI_CALL_BORDERLINE
+                if (is_call) mask |= 1u << nt;
+                if ((is_call || near_gate) && n_calls) {
+                    const long long idx = call_slot(n_calls, capacity);
+                    if (calls && idx >= 0) {
+                        ampli_call c;
+                        call_fill(c, t, (int)r, nt, RD, q_fw, q_bw, k_fw, k_bw, FW, BW, near_gate ? AMPLI_CALL_BORDERLINE : 0);
+                        calls[idx] = c;
                     }
                 }
             }
@@ -1622,8 +1623,13 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
             // Q is NaN and VC:898 is false
         }
         const double q_other = __shfl_xor(qv, 1);
-        const bool emit = on && strand == 0 && qv >= 5 && q_other >= 5; // VC:898 (coverage was checked before queueing)
-        if (emit) {
+        const bool is_call = on && strand == 0 && qv >= 5 && q_other >= 5; // VC:898 (coverage was checked before queueing)
+        // a Q within 1e-6 of the gate cannot be decided here (include/amplisolve_hip.h, AMPLI_CALL_BORDERLINE): the pair goes
+        // on the list either way, flagged, for the host to re-evaluate with the reference's own operation sequence
+        const double lo = 5.0 - AMPLI_CALL_GATE_EPS, hi = 5.0 + AMPLI_CALL_GATE_EPS;
+        const bool near_gate = on && strand == 0 && qv >= lo && q_other >= lo && (qv < hi || q_other < hi);
+        const bool emit = is_call || near_gate;
+        if (is_call) {
             const int record = it.record_alt & 0x3FFFFFFF, alt = (it.record_alt >> 30) & 3;
             const size_t o = (size_t)it.sample * R + record;
             atomicOr(&mask_words[o >> 2], (1u << alt) << ((o & 3) * 8));
@@ -1641,7 +1647,8 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
                     const long long idx = (long long)base + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
                     if (idx < per) {
                         ampli_call c;
-                        call_fill(c, it.sample, it.record_alt & 0x3FFFFFFF, (it.record_alt >> 30) & 3, it.rd, qv, q_other, it.k_fw, it.k_bw, it.FW, it.BW);
+                        call_fill(c, it.sample, it.record_alt & 0x3FFFFFFF, (it.record_alt >> 30) & 3, it.rd, qv, q_other, it.k_fw, it.k_bw, it.FW, it.BW,
+                                  near_gate ? AMPLI_CALL_BORDERLINE : 0);
                         calls[(size_t)cs * per + idx] = c;
                     }
                 }

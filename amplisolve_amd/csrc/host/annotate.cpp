@@ -3,9 +3,36 @@
 #include <algorithm>
 #include <cmath>
 
+#include "../ampli_math.h"
 #include "host.hpp"
 
 namespace ampli {
+
+// Decision guard for calls within rounding of the gates (include/amplisolve_hip.h, AMPLI_CALL_BORDERLINE): the reference's
+// own operation sequence for Q -- kf_gammaq in double with the host's libm, the final log10 in x87 long double
+// (VC:3834-3884, line for line: err == -1 -> -888, err == 0 -> 0.0010008f, k == 0 -> p = 1, p < 1e-10 -> -10*log10l(1e-10),
+// p == 1 -> 0).  Only ever called for the handful of emitted pairs whose device Q lies within 1e-6 of 5 or of 20.
+long double score_reference_sequence(int k, int rd, float err)
+{
+    if (err == -1) return -888;
+    if (err == 0) err = 0.0010008;
+    double p;
+    if (k == 0) p = 1;
+    else {
+        const double m = double(rd) * err;
+        p = 1 - ampli_kf_gammaq(k, m);
+    }
+    long double Q;
+    if (p < 0.0000000001) {
+        p = 0.0000000001;
+        Q = -10 * log10l(p);
+    } else if (p == 1) {
+        Q = 0;
+    } else {
+        Q = -10 * log10l(p);
+    }
+    return Q;
+}
 
 // Two-sided Fisher exact test as VC:3797-3814 forms it: N = a+b+c+d, r = a+c, n = c+d, sum of the
 // hypergeometric pmf over all k whose probability does not exceed that of the observed k = c.

@@ -158,6 +158,7 @@ int run_error_estimation(const EeArgs &a);
 int run_variant_calling(const VcArgs &a);
 // ---- annotate.cpp ----
 double fisher_two_sided(int a, int b, int c, int d);                            // VC:3797-3814 (own hypergeometric pmf)
+long double score_reference_sequence(int k, int rd, float err);                 // VC:3834-3884, for calls within rounding of a gate
 std::string kmer_down(const Panel &p, const std::string &chrom, int pos);       // VC:3307-3458
 std::string kmer_up(const Panel &p, const std::string &chrom, int pos);         // VC:3461-3613
 int homopolymer_test(const std::string &down, const std::string &up, char sub); // VC:3615-3718

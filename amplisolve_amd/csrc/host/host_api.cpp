@@ -199,6 +199,14 @@ extern "C" int ampli_host_run_variant_calling_sharded(const char *error_file, co
 
 extern "C" double ampli_host_fisher(int a, int b, int c, int d) { return fisher_two_sided(a, b, c, d); }
 
+extern "C" double ampli_host_guard_score(int32_t k, int32_t rd, float err, int32_t *ge5, int32_t *lt20)
+{
+    const long double q = score_reference_sequence(k, rd, err);
+    if (ge5) *ge5 = q >= 5 ? 1 : 0;   // the comparisons of VC:898 / VC:1023, in long double like the reference's
+    if (lt20) *lt20 = q < 20 ? 1 : 0;
+    return (double)q;
+}
+
 extern "C" int ampli_host_sample_order(const char *dir, char *out, int64_t cap)
 {
     try {

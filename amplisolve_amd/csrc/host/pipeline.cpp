@@ -373,6 +373,7 @@ struct CallRow {
     double q_fw, q_bw;
     float af, af_fw, af_bw;
     int rd, fw, bw, k_fw, k_bw; // the evidence of the call, as the kernel saw it
+    int flags;                  // AMPLI_CALL_*
 };
 
 } // namespace
@@ -493,7 +494,7 @@ int run_variant_calling(const VcArgs &a)
                             const int line = prim ? c->line_prim[(size_t)cl.sample * P + cl.record] : c->line_ext[(size_t)cl.sample * c->E + (cl.record - P)];
                             const int64_t pp = prim ? (int64_t)cl.record : (int64_t)c->ext_pos[(size_t)(cl.record - P)];
                             rows.push_back(CallRow{c->first + cl.sample, line, cl.alt, pp, cl.q_fw, cl.q_bw, cl.af, cl.af_fw, cl.af_bw, cl.rd, cl.fw,
-                                                   cl.bw, cl.k_fw, cl.k_bw});
+                                                   cl.bw, cl.k_fw, cl.k_bw, cl.flags});
                         }
                     }
                     done = true;
@@ -507,6 +508,28 @@ int run_variant_calling(const VcArgs &a)
             parse_s = cs.parse_seconds();
         }
         const double t2 = now_s();
+        // Calls within rounding of a gate.  The device forms Q in fp64 with ROCm's exp / log, the reference with glibc and an
+        // x87 long double log10 (VC:3866-3880); they agree to ~1e-10, so a pair whose device Q lies within 1e-6 of the call
+        // gate Q >= 5 (VC:898; flagged by the kernel, listed either way) or of the LowQ threshold Q < 20 (VC:1023) is
+        // re-evaluated here with the reference's own operation sequence before it is gated, flagged or printed.
+        int64_t n_guarded = 0, n_dropped = 0;
+        {
+            std::vector<CallRow> kept;
+            kept.reserve(rows.size());
+            for (CallRow &c : rows) {
+                auto near = [](double q, double gate) { return std::fabs(q - gate) <= AMPLI_CALL_GATE_EPS; };
+                if ((c.flags & AMPLI_CALL_BORDERLINE) || near(c.q_fw, 20) || near(c.q_bw, 20)) {
+                    ++n_guarded;
+                    const long double qf = score_reference_sequence(c.k_fw, c.rd - c.bw, thr[(size_t)(0 * 4 + c.alt) * P + c.p]); // VC:895
+                    const long double qb = score_reference_sequence(c.k_bw, c.bw, thr[(size_t)(1 * 4 + c.alt) * P + c.p]);        // VC:896
+                    if (!(qf >= 5 && qb >= 5)) { ++n_dropped; continue; } // VC:898 in the reference's own arithmetic
+                    c.q_fw = (double)qf;
+                    c.q_bw = (double)qb;
+                }
+                kept.push_back(c);
+            }
+            rows.swap(kept);
+        }
         // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
         std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
             if (x.sample != y.sample) return x.sample < y.sample;
@@ -604,7 +627,7 @@ int run_variant_calling(const VcArgs &a)
         }
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING table " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done << " parse_busy "
-                      << parse_s << " calls " << rows.size() << "\nTIMING annotate+write " << now_s() - t2 << std::endl;
+                      << parse_s << " calls " << rows.size() << " guarded " << n_guarded << " dropped_by_guard " << n_dropped << "\nTIMING annotate+write " << now_s() - t2 << std::endl;
         std::cout << "\nAmpliSolveVariantCalling execution was successful. The results can be found at : " << summary << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;

@@ -307,8 +307,16 @@ typedef struct ampli_call {
     float af, af_fw, af_bw;       /* VC:772-817: the reported VAFs */
     int32_t k_fw, k_bw;           /* alt reads per strand (Xfw = X - Xrs, Xrs) */
     int32_t fw, bw;               /* strand depths: sums of the four forward / reverse counts (VC:760-761) */
-    int32_t pad;
+    int32_t flags;                /* AMPLI_CALL_* */
 } ampli_call; /* 64 bytes */
+
+/* ampli_call.flags.  The device forms Q = -10 log10 p in fp64 with ROCm's exp / log, the reference in glibc's double and
+ * x87 long double (VC:3866-3880): the two agree to ~1e-10, so a Q within 1e-6 of the gate Q >= 5 (VC:898) cannot be decided on
+ * the device.  Such (record, alternative) pairs are put on the call list EITHER WAY with AMPLI_CALL_BORDERLINE set; the mask
+ * bit follows the device's own value, and the host re-evaluates the pair with the reference's operation sequence before it
+ * writes anything (csrc/host/annotate.cpp: score_reference_sequence).  None occurs on Toy_data or the synthetic panels. */
+#define AMPLI_CALL_BORDERLINE 1
+#define AMPLI_CALL_GATE_EPS 1e-6
 
 #define AMPLI_CALL_SHARDS 32
 #define AMPLI_CALL_COUNTER_STRIDE 16 /* uint64 words between shard counters: one 128-byte line each */

@@ -127,6 +127,11 @@ int ampli_host_run_error_estimation_sharded(const char *panel_design, const char
 int ampli_host_run_variant_calling_sharded(const char *error_file, const char *tumour_dir, const char *output_dir,
                                            const char *coverage_cutoff, const char *p_value, const ampli_host_shard *shard);
 
+/* the decision guard of the variant-calling command line for calls within 1e-6 of a gate (AMPLI_CALL_BORDERLINE): Q by the
+ * reference's own operation sequence (VC:3834-3884: double kf_gammaq, long double log10); *ge5 / *lt20 = the comparisons of
+ * VC:898 / VC:1023 made in long double */
+double ampli_host_guard_score(int32_t k, int32_t rd, float err, int32_t *ge5, int32_t *lt20);
+
 /* two-sided Fisher exact test of the post-call annotation (VC:3797-3814; own pmf, parity unpinned vs Boost) */
 double ampli_host_fisher(int a, int b, int c, int d);
 

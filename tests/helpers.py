@@ -45,3 +45,33 @@ def edge_case_recs(P, S, rng):
     recs[absent] = 0
     recs[absent, 0] = np.iinfo(np.int32).min
     return recs
+
+
+def borderline_triples(want=12, seed=5, gate=5.0, eps=1e-6, errs=(0.000001, 0.000002, 0.000003, 0.000005, 0.000007, 0.000011, 0.000013)):
+    """(k, RD, err, Q) with the REFERENCE's Q (the oracle's scorer is bit-identical to it, tests/test_oracle_golden.py) within
+    eps of the gate, on both sides of it.  err has at most six decimals so that it survives the error table's "%f"; the fine
+    knob is RD: Q falls as RD grows, bisection finds the crossing and its neighbours are kept when they are close enough."""
+    from oracle import pyoracle as orc
+
+    L = orc.lib()
+    rng = np.random.default_rng(seed)
+    out = []
+    tries = 0
+    while len(out) < want and tries < 4000:
+        tries += 1
+        err = float(np.float32(rng.choice(errs)))
+        k = int(rng.integers(3, 60))
+        lo, hi = 100, (1 << 31) - 2  # Q(lo) high (tiny mean), Q(hi) low
+        if not (float(L.oracle_score(k, lo, err)) >= gate > float(L.oracle_score(k, hi, err))):
+            continue
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if float(L.oracle_score(k, mid, err)) >= gate:
+                lo = mid
+            else:
+                hi = mid
+        for rd in (lo - 1, lo, hi, hi + 1):
+            q = float(L.oracle_score(k, rd, err))
+            if abs(q - gate) <= eps and (k, rd, err) not in [(a, b, c) for a, b, c, _ in out]:
+                out.append((k, rd, err, q))
+    return out

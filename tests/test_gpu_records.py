@@ -210,3 +210,39 @@ def test_lines_with_their_own_rd_column(ctx, layout):
             r = trecs[c["sample"], c["record"]]
             want_rd = trd[c["sample"], c["record"]] if trd[c["sample"], c["record"]] != ABSENT else r.sum()
             assert c["rd"] == want_rd and np.float32(c["af"]) == exp["af"][c["sample"], c["record"], c["alt"], 0]
+
+
+def test_calls_within_rounding_of_the_gate_are_flagged_and_decided_by_the_guard(ctx):
+    """(k, RD, err) whose REFERENCE Q lies within 1e-6 of the gate Q >= 5, on both sides of it: the device cannot decide
+    them (its exp / log differ from glibc's in the last bits), so it lists every one of them with AMPLI_CALL_BORDERLINE --
+    above or below -- and the host's guard, which repeats the reference's operation sequence, decides as the reference."""
+    import ctypes as C
+
+    from amplisolve_amd import host_lib
+    from amplisolve_amd.api import POISSON_FULL, POISSON_PREFILTER
+    from tests.helpers import borderline_triples
+
+    tri = borderline_triples(16)
+    assert len(tri) >= 8 and any(q >= 5 for *_, q in tri) and any(q < 5 for *_, q in tri)
+    P, T = len(tri), 2
+    trecs = np.zeros((T, P, 8), np.int32)
+    thr = np.full((2, 4, P), 0.002, np.float32)
+    for i, (k, rd, err, _) in enumerate(tri):
+        trecs[:, i] = [rd - k, k, 0, 0, 950, 50, 0, 0]  # reference A; alt C: forward strand on the knife edge, reverse Q = 100
+        thr[0, 1, i] = err
+    ref_code = np.zeros(P, np.uint8)
+    exp = orc.poisson_call(trecs, P, thr, ref_code, 100)
+    want = {(t, i): bool(exp["call_mask"][t, i] >> 1 & 1) for t in range(T) for i in range(P)}
+    assert any(want.values()) and not all(want.values())
+    H = host_lib()
+    for mode in (POISSON_PREFILTER, POISSON_FULL):
+        res = ctx.poisson_call(_t(trecs), P, _t(thr), _t(ref_code), 100, mode=mode, capacity=32 * 4 * P * T)
+        calls = [c for c in ctx.read_calls(res) if c["alt"] == 1]
+        assert {(c["sample"], c["record"]) for c in calls} == set(want)  # every pair is listed, called or not
+        for c in calls:
+            assert c["flags"] & 1  # AMPLI_CALL_BORDERLINE
+            k, rd, err, q = tri[c["record"]]
+            assert abs(c["q_fw"] - q) < 1e-6 and c["q_bw"] == 100.0 and (c["k_fw"], c["rd"] - c["bw"]) == (k, rd)
+            ge5 = C.c_int32()
+            got = H.ampli_host_guard_score(int(c["k_fw"]), int(c["rd"] - c["bw"]), float(thr[0, 1, c["record"]]), C.byref(ge5), None)
+            assert got == q and bool(ge5.value) == want[(c["sample"], c["record"])]

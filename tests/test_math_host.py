@@ -156,3 +156,21 @@ def test_division_free_series_of_the_drain_kernel_is_the_reference_series():
         assert np.array_equal(q >= thr, qo >= thr), thr
     fin = qo < 100
     assert np.max(np.abs(q[fin] - qo[fin])) < 1e-7
+
+
+def test_decision_guard_is_the_reference_operation_sequence():
+    """The host re-evaluates calls within 1e-6 of a gate with the reference's own sequence (double kf_gammaq, long double
+    log10; csrc/host/annotate.cpp).  On the golden grid produced by the reference's compiled scorer it must return the very
+    doubles, and its >= 5 / < 20 decisions must be the long-double ones."""
+    import os
+
+    H = host_lib()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vc_scorer_reference.npz"))
+    k, rd, err, q = g["k"], g["rd"], g["err"], g["q"]
+    ge5, lt20 = C.c_int32(), C.c_int32()
+    idx = np.random.default_rng(3).choice(k.size, min(k.size, 20000), replace=False)
+    for i in idx:
+        got = H.ampli_host_guard_score(int(k[i]), int(rd[i]), float(err[i]), C.byref(ge5), C.byref(lt20))
+        assert (got == q[i]) or (np.isnan(got) and np.isnan(q[i])), (k[i], rd[i], err[i], got, q[i])
+        if not np.isnan(q[i]) and abs(q[i] - 5) > 1e-9 and abs(q[i] - 20) > 1e-9:
+            assert ge5.value == int(q[i] >= 5) and lt20.value == int(q[i] < 20)
