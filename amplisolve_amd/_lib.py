@@ -85,6 +85,14 @@ HIP_SYMBOLS = {
     "ampli_error_finalize": (C.c_int, [vp, C.POINTER(AccTable), f32, i32, vp, vp, vp, vp, vp, vp]),
     "ampli_poisson_call": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
     "ampli_poisson_call_blocks": (C.c_int, [vp, vp, i64, i64, vp, i32, vp, i32, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
+    "ampli_comm_create": (C.c_int, [vp, i32, i32, C.c_char_p, i32, C.POINTER(vp)]),
+    "ampli_comm_destroy": (None, [vp]),
+    "ampli_comm_reduce_scatter_f64": (C.c_int, [vp, vp, vp, i64]),
+    "ampli_comm_all_to_all_f32": (C.c_int, [vp, vp, vp, i64]),
+    "ampli_comm_all_gather_bytes": (C.c_int, [vp, vp, vp, i64]),
+    "ampli_comm_all_reduce_max_i32": (C.c_int, [vp, C.POINTER(i32), i32]),
+    "ampli_comm_exclusive_sum_i64": (C.c_int, [vp, i64, C.POINTER(i64)]),
+    "ampli_comm_barrier": (C.c_int, [vp]),
     "ampli_score_batch": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
     "ampli_roundtrip_batch": (C.c_int, [vp, vp, i64, vp]),
     "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),

@@ -376,6 +376,22 @@ int ampli_graph_end(ampli_ctx *ctx, void **graph_exec);
 int ampli_graph_launch(ampli_ctx *ctx, void *graph_exec);
 int ampli_graph_destroy(void *graph_exec);
 
+/*
+ * Native transport of the multi-GPU merge (one process per GPU, no Python): RCCL over xGMI, bound at run time
+ * (librccl.so is only loaded when a communicator is created).  Rendezvous through a file every rank can see: rank 0
+ * writes its ncclUniqueId there, the others wait up to timeout_s for it.  Collectives are enqueued on the context's
+ * stream; the *_i32 / *_i64 helpers take HOST values and synchronise.  Buffer shapes as in "Position-sliced merge".
+ */
+typedef struct ampli_comm ampli_comm;
+int ampli_comm_create(ampli_ctx *ctx, int32_t rank, int32_t world, const char *id_file, int32_t timeout_s, ampli_comm **out);
+void ampli_comm_destroy(ampli_comm *c);
+int ampli_comm_reduce_scatter_f64(ampli_comm *c, const double *d_send /*[world][count]*/, double *d_recv /*[count]*/, int64_t count);
+int ampli_comm_all_to_all_f32(ampli_comm *c, const float *d_send /*[world][count]*/, float *d_recv /*[world][count]*/, int64_t count);
+int ampli_comm_all_gather_bytes(ampli_comm *c, const void *d_send /*[bytes]*/, void *d_recv /*[world][bytes]*/, int64_t bytes);
+int ampli_comm_all_reduce_max_i32(ampli_comm *c, int32_t *values /*host, in place*/, int32_t n);
+int ampli_comm_exclusive_sum_i64(ampli_comm *c, int64_t mine, int64_t *before);
+int ampli_comm_barrier(ampli_comm *c);
+
 /* scalar scorer on the device for known-answer tests: q[i] = score(k[i], rd[i], err[i]),
  * p[i] = 1 - kf_gammaq(k, rd*err) (VC:3834-3884).  Either output may be NULL. */
 int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err,
