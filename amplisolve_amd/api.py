@@ -161,7 +161,7 @@ class Context:
         return (recs, True) if layout == "i32" else (self.pack16(recs) if layout == "u16" else self.pack24(recs))
 
     def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
-        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general) | (groups << 4)))
+        self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general), groups))
 
     # ---- hipGraph capture ---------------------------------------------------------------
     def graph_begin(self):

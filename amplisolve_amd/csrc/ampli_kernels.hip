@@ -311,12 +311,13 @@ extern "C" int ampli_set_slice_group(ampli_ctx *ctx, int32_t group_size, int32_t
     return AMPLI_OK;
 }
 
-extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general)
+extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general, int32_t reduce_lane_groups)
 {
-    if (!ctx || reduce_sample_splits < 0) return AMPLI_E_INVALID;
+    if (!ctx || reduce_sample_splits < 0 || (reduce_lane_groups != 0 && reduce_lane_groups != 1 && reduce_lane_groups != 2 && reduce_lane_groups != 4))
+        return AMPLI_E_INVALID;
     ctx->reduce_splits = reduce_sample_splits;
-    ctx->reduce_general = reduce_general & 1;
-    ctx->reduce_groups = (reduce_general >> 4) & 7; // bits 4-6: lane groups per wave (0 = auto)
+    ctx->reduce_general = reduce_general ? 1 : 0;
+    ctx->reduce_groups = reduce_lane_groups; // lane groups per wave (0 = auto)
     return AMPLI_OK;
 }
 
@@ -345,20 +346,8 @@ extern "C" int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear)
     return AMPLI_OK;
 }
 
-// streaming 16-byte load of record data (read once per launch): optionally non-temporal
-#ifndef AMPLI_NT_LOADS
-#define AMPLI_NT_LOADS 0
-#endif
-__device__ __forceinline__ int4 ld_stream(const int4 *p)
-{
-#if AMPLI_NT_LOADS
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    const v4i v = __builtin_nontemporal_load((const v4i *)p);
-    return make_int4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
+// streaming 16-byte load of record data (default cache policy: non-temporal loads measured 4-10 % slower)
+__device__ __forceinline__ int4 ld_stream(const int4 *p) { return *p; }
 
 // Record layouts (include/amplisolve_hip.h), template parameter LAY:
 //   AMPLI_RECORDS_I32  8 x int32, two int4 per record                      (absent: INT32_MIN in field 0)
@@ -831,21 +820,13 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
     const double prod_bw = (double)((float)BW * C); // EE:1599
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-#if defined(AMPLI_DIAG_NOTHR)
-        if (covok && fw[nt] == -77 && bw[nt] <= lim_bw) {
-#else
         if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
-#endif
             a.sx[0][nt] += fw[nt]; a.sd[0][nt] += FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
             a.sx[1][nt] += bw[nt]; a.sd[1][nt] += BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
             a.cnt[nt] += 1;                                                   // EE:1606
         }
         const int x = fw[nt] + bw[nt];
-#if defined(AMPLI_DIAG_NOGM)
-        const bool pass = covok && x == -77;
-#else
         const bool pass = covok && x <= lim_rd; // EE:1251: float(X)/float(RD) <= 0.05
-#endif
         if (LEAN) {
             // straight-line steady state: every passing lane already holds its first record, so only "x/RD > best" is
             // left (EE:1266).  A lane meeting its FIRST qualifying record (its AF is dropped by the reference,

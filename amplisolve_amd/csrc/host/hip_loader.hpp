@@ -37,7 +37,7 @@ struct HipApi {
                                int32_t, double *, float *);
     int (*error_finalize_slice)(ampli_ctx *, int64_t, int32_t, int32_t, const double *, const float *, float, int32_t, void *);
     int (*error_table_unslice)(ampli_ctx *, int64_t, int32_t, const void *, float *, uint8_t *, float *, float *, uint8_t *, int32_t *);
-    int (*set_tuning)(ampli_ctx *, int32_t, int32_t);
+    int (*set_tuning)(ampli_ctx *, int32_t, int32_t, int32_t);
     int (*ctx_flags)(ampli_ctx *, int32_t *, int32_t);
     int (*set_queue_items)(ampli_ctx *, int64_t);
     int (*poisson_call)(ampli_ctx *, const int32_t *, int64_t, int64_t, const uint32_t *, int32_t, const float *,
@@ -53,6 +53,15 @@ struct HipApi {
     int (*event_destroy)(void *);
     int (*event_record)(ampli_ctx *, void *);
     int (*event_sync)(void *);
+    // native transport of the multi-GPU merge (RCCL over xGMI, include/amplisolve_hip.h "ampli_comm")
+    int (*comm_create)(ampli_ctx *, int32_t, int32_t, const char *, int32_t, ampli_comm **);
+    void (*comm_destroy)(ampli_comm *);
+    int (*comm_reduce_scatter_f64)(ampli_comm *, const double *, double *, int64_t);
+    int (*comm_all_to_all_f32)(ampli_comm *, const float *, float *, int64_t);
+    int (*comm_all_gather_bytes)(ampli_comm *, const void *, void *, int64_t);
+    int (*comm_all_reduce_max_i32)(ampli_comm *, int32_t *, int32_t);
+    int (*comm_exclusive_sum_i64)(ampli_comm *, int64_t, int64_t *);
+    int (*comm_barrier)(ampli_comm *);
 };
 
 const HipApi *hip_api(std::string *why);

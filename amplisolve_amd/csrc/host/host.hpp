@@ -144,15 +144,26 @@ void panel_from_error_table(const std::string &path, const std::string &dummy_vc
 struct HipApi; // function pointers of libamplisolve_hip.so
 const HipApi *hip_api(std::string *why = nullptr); // nullptr when the library cannot be loaded
 // ---- pipeline.cpp ----
+// one process per GPU without Python: this process is shard `rank` of `world`, the exchange steps go over RCCL
+// (ampli_comm_* of include/amplisolve_hip.h); rank 0 publishes the communicator id in id_file
+struct NativeDist {
+    int rank = 0, world = 1;
+    std::string id_file;
+    int timeout_s = 120;
+};
+// AMPLISOLVE_WORLD_SIZE / AMPLISOLVE_RANK / AMPLISOLVE_ID_FILE / AMPLISOLVE_RCCL_TIMEOUT (the executables' multi-GPU mode)
+NativeDist native_dist_from_env(const std::string &output_dir);
 struct EeArgs {
     std::string panel_design, reference_genome, germline_dir, output_dir;
     std::string C_value = "0.002", coverage_cutoff = "100", default_error = "0.01";
     std::string refbases_file; // test hook: skip the FASTA, read chrom/pos/base lines
     const ampli_host_shard *shard = nullptr; // one shard of a multi-process run (include/amplisolve_host.h)
+    NativeDist native;                       // or: one shard with the library's own RCCL transport (shard == nullptr)
 };
 struct VcArgs {
     std::string error_file, tumour_dir, output_dir, coverage_cutoff = "100", p_value = "0.05";
     const ampli_host_shard *shard = nullptr;
+    NativeDist native;
 };
 int run_error_estimation(const EeArgs &a);
 int run_variant_calling(const VcArgs &a);

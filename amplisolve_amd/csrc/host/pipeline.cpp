@@ -161,9 +161,126 @@ ampli_records upload_chunk(Dev &dev, DevSlot &ds, const Chunk &c, bool for_calli
     return r;
 }
 
+// The multi-GPU mode of the executables themselves (one process per GPU, no Python): the exchange steps of
+// ampli_host_shard over the HIP library's own RCCL transport (ampli_comm_*).  Owns a context on the device's default
+// stream -- the stream the pipeline's kernels run on -- so every collective is ordered with the kernels around it.
+struct NativeShard {
+    Dev dev;
+    ampli_comm *comm = nullptr;
+    ampli_host_shard hooks;
+    NativeDist nd;
+    std::string err;
+    bool active = false;
+
+    NativeShard() { memset(&hooks, 0, sizeof hooks); }
+    ~NativeShard()
+    {
+        if (comm) dev.api->comm_destroy(comm);
+    }
+    void describe(const NativeDist &d)
+    {
+        nd = d;
+        active = d.world > 1 || getenv("AMPLISOLVE_FORCE_NATIVE_DIST") != nullptr; // forced: the RCCL path on a communicator of one
+        hooks.index = d.rank; hooks.count = d.world; hooks.user = this;
+        hooks.ee_buffers = &NativeShard::s_buffers; hooks.ee_exchange = &NativeShard::s_exchange; hooks.ee_gather = &NativeShard::s_gather;
+        hooks.or_flags = &NativeShard::s_or_flags; hooks.rows_before = &NativeShard::s_rows_before; hooks.barrier = &NativeShard::s_barrier;
+    }
+    // every rank gets here before it parses anything, so the rendezvous does not wait for the slowest parser
+    void open()
+    {
+        std::string why;
+        const HipApi *api = hip_api(&why);
+        if (!api) throw Error{AMPLI_E_HIP, "libamplisolve_hip.so could not be loaded (" + why + "); there is no CPU fallback"};
+        if (!getenv("AMPLISOLVE_DEVICE")) { // one GPU per process: rank k takes device k (mod the visible ones)
+            const int n = api->device_count();
+            if (n <= 0) throw Error{AMPLI_E_HIP, "no MI355X visible; there is no CPU fallback"};
+            setenv("AMPLISOLVE_DEVICE", std::to_string(nd.rank % n).c_str(), 1);
+        }
+        if (nd.id_file.empty()) throw Error{AMPLI_E_INVALID, "multi-GPU run: AMPLISOLVE_ID_FILE (a path every process can see) is not set"};
+        dev.open();
+        dev.check(dev.api->comm_create(dev.ctx, nd.rank, nd.world, nd.id_file.c_str(), nd.timeout_s, &comm), "ampli_comm_create");
+        dev.check(dev.api->comm_barrier(comm), "ampli_comm_barrier"); // every rank has read the id
+        if (nd.rank == 0) std::remove(nd.id_file.c_str());
+    }
+
+    size_t sums_b = 0, gm_b = 0, block_b = 0;
+    int64_t L = 0;
+    void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    template <class F> static int guarded(void *user, F &&f)
+    {
+        NativeShard *s = (NativeShard *)user;
+        try {
+            f(*s);
+            return 0;
+        } catch (const Error &e) {
+            s->err = e.msg;
+            return e.code ? e.code : -1;
+        }
+    }
+    static int s_buffers(void *user, int64_t P, void **out)
+    {
+        return guarded(user, [&](NativeShard &s) {
+            const int n = s.nd.world;
+            s.L = s.dev.api->slice_len(P, n);
+            s.dev.check(s.dev.api->slice_bytes(P, n, &s.sums_b, &s.gm_b, &s.block_b), "ampli_slice_bytes");
+            const size_t sizes[6] = {s.sums_b, s.gm_b, s.sums_b / (size_t)n, s.gm_b, s.block_b, s.block_b * (size_t)n};
+            for (int i = 0; i < 6; ++i) {
+                s.bufs[i] = s.dev.alloc<char>(sizes[i]);
+                s.dev.check(s.dev.api->memset_d(s.dev.ctx, s.bufs[i], 0, sizes[i]), "ampli_memset_d"); // padding positions are never written
+                out[i] = s.bufs[i];
+            }
+        });
+    }
+    static int s_exchange(void *user)
+    {
+        return guarded(user, [&](NativeShard &s) {
+            s.dev.check(s.dev.api->comm_reduce_scatter_f64(s.comm, (const double *)s.bufs[0], (double *)s.bufs[2], 21 * s.L), "ampli_comm_reduce_scatter_f64");
+            s.dev.check(s.dev.api->comm_all_to_all_f32(s.comm, (const float *)s.bufs[1], (float *)s.bufs[3], 8 * s.L), "ampli_comm_all_to_all_f32");
+        });
+    }
+    static int s_gather(void *user)
+    {
+        return guarded(user, [&](NativeShard &s) {
+            s.dev.check(s.dev.api->comm_all_gather_bytes(s.comm, s.bufs[4], s.bufs[5], (int64_t)s.block_b), "ampli_comm_all_gather_bytes");
+        });
+    }
+    static int s_or_flags(void *user, int32_t *flags)
+    {
+        return guarded(user, [&](NativeShard &s) {
+            int32_t bits[31];
+            for (int b = 0; b < 31; ++b) bits[b] = (*flags >> b) & 1;
+            s.dev.check(s.dev.api->comm_all_reduce_max_i32(s.comm, bits, 31), "ampli_comm_all_reduce_max_i32");
+            int32_t v = 0;
+            for (int b = 0; b < 31; ++b) v |= bits[b] ? (1 << b) : 0;
+            *flags = v;
+        });
+    }
+    static int s_rows_before(void *user, int64_t mine, int64_t *before)
+    {
+        return guarded(user, [&](NativeShard &s) { s.dev.check(s.dev.api->comm_exclusive_sum_i64(s.comm, mine, before), "ampli_comm_exclusive_sum_i64"); });
+    }
+    static int s_barrier(void *user)
+    {
+        return guarded(user, [&](NativeShard &s) { s.dev.check(s.dev.api->comm_barrier(s.comm), "ampli_comm_barrier"); });
+    }
+};
+
 const char *kLine = "************************************************************************************************************************************";
 
 } // namespace
+
+NativeDist native_dist_from_env(const std::string &output_dir)
+{
+    NativeDist d;
+    if (const char *e = getenv("AMPLISOLVE_WORLD_SIZE")) d.world = std::max(1, atoi(e));
+    if (const char *e = getenv("AMPLISOLVE_RANK")) d.rank = atoi(e);
+    if (d.rank < 0 || d.rank >= d.world) { d.rank = 0; d.world = 1; }
+    if (const char *e = getenv("AMPLISOLVE_ID_FILE")) d.id_file = e;
+    else if (!output_dir.empty()) d.id_file = output_dir + "/.amplisolve_rccl_id"; // output_dir is shared by all processes anyway
+    if (const char *e = getenv("AMPLISOLVE_RCCL_TIMEOUT")) d.timeout_s = std::max(1, atoi(e));
+    return d;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 int run_error_estimation(const EeArgs &a)
@@ -206,8 +323,19 @@ int run_error_estimation(const EeArgs &a)
         std::cout << "\t6. Output dir                                     : " << a.output_dir << std::endl;
 
         const ampli_host_shard *sh = (a.shard && a.shard->count > 1) ? a.shard : nullptr;
+        NativeShard native; // the executables' own multi-GPU mode (RCCL); callers with their own transport pass a.shard
+        if (!sh) {
+            native.describe(a.native);
+            if (native.active) {
+                mkdir_p(a.output_dir); // the default id file lives there
+                native.open();
+                sh = &native.hooks;
+            }
+        }
         const bool writer = !sh || sh->index == 0; // shard 0 writes every file of a multi-process run
-        auto hook = [&](int rc, const char *what) { if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what}; };
+        auto hook = [&](int rc, const char *what) {
+            if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what + (native.err.empty() ? "" : " -- " + native.err)};
+        };
         const std::string interm = a.output_dir + "/AmpliSolveErrorEstimation_interm_files"; // EE:414
         if (writer) mkdir_p(interm);
         srand((unsigned)time(nullptr));
@@ -298,7 +426,7 @@ int run_error_estimation(const EeArgs &a)
             dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
             if (sh) hook(sh->or_flags(sh->user, &kflags), "or_flags");
             if (!(kflags & AMPLI_FLAG_RERUN_GENERAL) || attempt == 1) break;
-            dev.check(dev.api->set_tuning(dev.ctx, 0, 1), "ampli_set_tuning"); // a depth beyond the fast kernel (on some shard): all stream again
+            dev.check(dev.api->set_tuning(dev.ctx, 0, 1, 0), "ampli_set_tuning"); // a depth beyond the fast kernel (on some shard): all stream again
             dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
         }
         double t2 = now_s();
@@ -405,8 +533,19 @@ int run_variant_calling(const VcArgs &a)
         std::cout << std::endl;
 
         const ampli_host_shard *sh = (a.shard && a.shard->count > 1) ? a.shard : nullptr;
+        NativeShard native;
+        if (!sh) {
+            native.describe(a.native);
+            if (native.active) {
+                mkdir_p(a.output_dir); // the default id file lives there
+                native.open();
+                sh = &native.hooks;
+            }
+        }
         const bool writer = !sh || sh->index == 0; // shard 0 writes the shared files of a multi-process run
-        auto hook = [&](int rc, const char *what) { if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what}; };
+        auto hook = [&](int rc, const char *what) {
+            if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what + (native.err.empty() ? "" : " -- " + native.err)};
+        };
         const std::string interm = a.output_dir + "/AmpliSolveVariantCalling_interm_files"; // VC:307
         mkdir_p(writer ? interm : a.output_dir);
         const double t0 = now_s();

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define AMPLI_ABI_VERSION 2
+#define AMPLI_ABI_VERSION 3
 #define AMPLI_ABSENT INT32_MIN
 /* record layouts, same field order in all of them:
  *   AMPLI_RECORDS_I32  int32 recs[n_samples][R][8], 32 B per record, absent: recs[..][0] == INT32_MIN
@@ -408,9 +408,9 @@ int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t see
 
 /* tuning knobs.  reduce_sample_splits: 0 = automatic.  reduce_general: 0 = the fast error_reduce kernel
  * (valid while every strand depth is < 2^22; it raises AMPLI_FLAG_RERUN_GENERAL otherwise), 1 = the literal
- * kernel that follows the reference operation by operation for any depth (slower).  Bits 4-6 of reduce_general
- * force the number of lane groups per wave (1, 2 or 4; 0 = automatic). */
-int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general);
+ * kernel that follows the reference operation by operation for any depth (slower).  reduce_lane_groups: lane
+ * groups per wave of error_reduce (1, 2 or 4; 0 = automatic: 1 unless the panel is too small to fill the chip). */
+int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general, int32_t reduce_lane_groups);
 
 /* poisson_call (prefilter mode) launch shape; 0 = default for each.  rows_per_wave: tumour rows one wave streams
  * (a workgroup = 4 waves over one 64-record tile and 4 * rows_per_wave rows).  drain_blocks_per_shard: workgroups per

@@ -145,3 +145,41 @@ def test_without_a_launcher_it_is_the_one_process_pipeline(tmp_path):
                         f"output_dir={out}"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (out / "positionSpecificNoise_0.0020.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0020.txt").read()
+
+
+# ---- the executables' own multi-GPU mode: no Python, RCCL transport of libamplisolve_hip.so (ampli_comm_*) ----
+def test_native_rccl_transport_both_command_lines_on_a_communicator_of_one(tmp_path):
+    """AMPLISOLVE_FORCE_NATIVE_DIST=1 sends a one-process run through the sharded pipeline over a REAL RCCL communicator
+    of size 1 (all a one-GPU box offers): id-file rendezvous, reduce-scatter, grouped send/recv all-to-all, all-gather,
+    all-reduce and the row-count gather all execute; outputs byte-identical to the plain run / the reference goldens."""
+    d = f"{G}/toy_subset"
+    env = dict(os.environ, AMPLISOLVE_STRICT_EXIT="1", AMPLISOLVE_FORCE_NATIVE_DIST="1", AMPLISOLVE_REFBASES_FILE=f"{d}/refbases.txt")
+    out = tmp_path / "native"
+    r = subprocess.run([f"{BIN}/AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
+                        "C_value=0.002", "coverage_cutoff=100", "default_error=0.01", f"output_dir={out}"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "shard 1/1" in r.stdout
+    assert (out / "positionSpecificNoise_0.0020.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0020.txt").read()
+    assert not os.path.exists(out / ".amplisolve_rccl_id")  # rank 0 removes the rendezvous file once everybody has read it
+
+    table = f"{d}/expected_positionSpecificNoise_0.0020.txt"
+    one, nat = tmp_path / "one", tmp_path / "native_vc"
+    for o, e in ((one, dict(os.environ, AMPLISOLVE_STRICT_EXIT="1")), (nat, env)):
+        r = subprocess.run([f"{BIN}/AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={d}/TUMOUR", f"output_dir={o}",
+                            "coverage_cutoff=100", "p_value=0.05"], capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (nat / "Summary_Variant_Info.txt").read_text() == (one / "Summary_Variant_Info.txt").read_text()
+    assert not [n for n in os.listdir(nat) if ".part" in n]
+
+
+def test_native_shard_without_rank_zero_fails_loudly(tmp_path):
+    """Rank 1 of 2 with nobody publishing the communicator id: a bounded wait, a message naming the file, exit status 1."""
+    d = f"{G}/toy_subset"
+    env = dict(os.environ, AMPLISOLVE_WORLD_SIZE="2", AMPLISOLVE_RANK="1", AMPLISOLVE_RCCL_TIMEOUT="2", AMPLISOLVE_DEVICE="0",
+               AMPLISOLVE_REFBASES_FILE=f"{d}/refbases.txt")
+    r = subprocess.run([f"{BIN}/AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
+                        "C_value=0.002", "coverage_cutoff=100", "default_error=0.01", f"output_dir={tmp_path}/o"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 1
+    assert "timed out waiting for rank 0's id file" in r.stdout

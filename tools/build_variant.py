@@ -10,6 +10,9 @@ SRC = os.path.join(ROOT, "amplisolve_amd", "csrc", "ampli_kernels.hip")
 OUT = os.path.join(ROOT, "_variants")
 
 V = {
+    # error_reduce without its threshold block / without its Germ_Max block (wrong results; where does the time go?)
+    "nothr": [("        if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595", "        if (covok && fw[nt] == -77 && bw[nt] <= lim_bw) { // variant: never")],
+    "nogm": [("        const bool pass = covok && x <= lim_rd; // EE:1251: float(X)/float(RD) <= 0.05", "        const bool pass = covok && x == -77; // variant: never")],
     # poisson_stream at whatever occupancy the register allocator picks (shipped: __launch_bounds__(256, 8))
     "lb256": [("template <int LAY>\n__global__ __launch_bounds__(256, 8) void poisson_stream_kernel(", "template <int LAY>\n__global__ __launch_bounds__(256) void poisson_stream_kernel(")],
     # poisson_stream without clearing the call mask (what do the mask stores cost?)
