@@ -65,7 +65,7 @@ def back_to_back(reps=40):
 
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 print(f"calls per launch {n_base}; algorithmic bytes {BYTES / 1e6:.1f} MB", flush=True)
-for rows in ([4, 8, 24] if quick else [2, 3, 4, 5, 6, 8, 12, 16, 24]):
+for rows in ([int(x) for x in os.environ["SWEEP_ROWS"].split(",")] if os.environ.get("SWEEP_ROWS") else [4, 8, 24] if quick else [2, 3, 4, 5, 6, 8, 12, 16, 24]):
     ctx.set_poisson_tuning(rows, 0)
     red, pc = in_loop()
     bb = back_to_back()
