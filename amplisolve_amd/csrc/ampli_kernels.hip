@@ -818,6 +818,7 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
     const int lim_fw = ampli_af_limit(FW), lim_bw = ampli_af_limit(BW), lim_rd = ampli_af_limit(RD);
     const double prod_fw = (double)((float)FW * C); // EE:1597
     const double prod_bw = (double)((float)BW * C); // EE:1599
+    const unsigned long long covmask = LEAN ? __builtin_amdgcn_ballot_w64(covok) : 0ull;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
@@ -832,7 +833,8 @@ __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4
             // left (EE:1266).  A lane meeting its FIRST qualifying record (its AF is dropped by the reference,
             // EE:1258-1261) is dealt with in the rare wave-uniform block and taken out of this row's comparison.
             bool cand = pass;
-            if (__builtin_amdgcn_ballot_w64(pass) & a.zmask[nt]) {
+            // the wave mask straight from the compare (a ballot of the bool costs a v_cndmask + v_cmp pair per nucleotide)
+            if ((__builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask) & a.zmask[nt]) {
                 const bool is_first = pass && a.gn[nt] == 0;
                 if (is_first) { a.gfx[nt] = x; a.gfd[nt] = RD; a.gfi[nt] = sample; a.gn[nt] = 1; }
                 a.zmask[nt] = __builtin_amdgcn_ballot_w64(a.gn[nt] == 0);
