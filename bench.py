@@ -632,6 +632,14 @@ def main():
     if lanes is not None:
         n_calls, fin = lanes[0][2]["n_calls"], lanes[0][1]
     n_found = int(n_calls[::CALL_COUNTER_STRIDE].sum().item())
+    # pairs within 1e-6 of the gate Q >= 5 (AMPLI_CALL_BORDERLINE): listed either way, re-evaluated by the command line with the
+    # reference's operation sequence -- counted here because every one of them is host work outside this step
+    n_borderline = None
+    if lanes is None and calls_buf is not None and cap > 0:
+        try:
+            n_borderline = int((ctx.read_calls(dict(n_calls=n_calls, calls_buf=calls_buf, capacity=cap))["flags"] & 1).sum())
+        except Exception:  # noqa: BLE001 -- a segment overflow is reported by the flags check, not here
+            n_borderline = None
     # the whole poisson_call (stream + drain kernels back to back), outside the timed region
     ctx.set_async_drain(False)
     e0, e1 = ctx.event(), ctx.event()
@@ -782,6 +790,7 @@ def main():
                         "R_EE_positions_per_s": P / (t_red * 1e-3), "R_VC_evals_per_s": P * T / (t_call * 1e-3),
                         "R_pipe_evals_per_s": P * T_total / (ms_per_step * 1e-3)},
             "calls_per_step": n_found,
+            "borderline_per_step": n_borderline,
         }
         if others:
             out["other_record_layouts"] = others

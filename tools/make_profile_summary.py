@@ -6,11 +6,17 @@ rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r02"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(f"{src}/trace/*/*kernel_stats.csv"):
+def newest(pattern):
+    """gpurun merges every call's files into the same local directory: only the latest run of a pass counts"""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
+for f in newest(f"{src}/trace/*/*kernel_stats.csv"):
     shutil.copy(f, f"{dst}/bench_c3_kernel_stats.csv")
 pm = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    for f in glob.glob(f"{src}/{d}/*/*counter_collection.csv"):
+    for f in newest(f"{src}/{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             pm[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
