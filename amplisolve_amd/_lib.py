@@ -93,6 +93,7 @@ HIP_SYMBOLS = {
     "ampli_comm_all_reduce_max_i32": (C.c_int, [vp, C.POINTER(i32), i32]),
     "ampli_comm_exclusive_sum_i64": (C.c_int, [vp, i64, C.POINTER(i64)]),
     "ampli_comm_barrier": (C.c_int, [vp]),
+    "ampli_pileup_count": (C.c_int, [vp, vp, vp, i64, vp, i64, i32, i32, vp, vp]),
     "ampli_score_batch": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
     "ampli_roundtrip_batch": (C.c_int, [vp, vp, i64, vp]),
     "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),
@@ -162,6 +163,8 @@ HOST_SYMBOLS = {
     "ampli_host_run_variant_calling": (C.c_int, [C.c_char_p] * 5),
     "ampli_host_run_error_estimation_sharded": (C.c_int, [C.c_char_p] * 8 + [C.POINTER(HostShard)]),
     "ampli_host_run_variant_calling_sharded": (C.c_int, [C.c_char_p] * 5 + [C.POINTER(HostShard)]),
+    "ampli_host_compute_counts": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, i32, i32, i32, i32, C.POINTER(i64)]),
+    "ampli_host_bam_scan": (C.c_int, [C.c_char_p, i32, C.POINTER(i64)]),
     "ampli_host_fisher": (C.c_double, [C.c_int] * 4),
     "ampli_host_guard_score": (C.c_double, [i32, i32, f32, C.POINTER(i32), C.POINTER(i32)]),
 }

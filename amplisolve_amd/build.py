@@ -66,8 +66,8 @@ def build_host(force: bool = False) -> str:
         os.path.join(CSRC, "ampli_math.h"), os.path.join(CSRC, "ampli_synth.h"),
         os.path.join(ROOT, "include", "amplisolve_host.h"), os.path.join(ROOT, "include", "amplisolve_hip.h")]
     if force or _newer(HOST_LIB, deps):
-        _run(["g++", *CXX_FLAGS, "-shared", "-o", HOST_LIB, *srcs, "-ldl"])
-    for exe, main in (("AmpliSolveErrorEstimation", "ee_main.cpp"), ("AmpliSolveVariantCalling", "vc_main.cpp")):
+        _run(["g++", *CXX_FLAGS, "-shared", "-o", HOST_LIB, *srcs, "-ldl", "-lz"])
+    for exe, main in (("AmpliSolveErrorEstimation", "ee_main.cpp"), ("AmpliSolveVariantCalling", "vc_main.cpp"), ("computeCounts", "cc_main.cpp")):
         msrc = os.path.join(hdir, main)
         out = os.path.join(BIN, exe)
         if os.path.exists(msrc) and (force or _newer(out, deps + [msrc, HOST_LIB])):

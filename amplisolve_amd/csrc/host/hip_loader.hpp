@@ -53,6 +53,7 @@ struct HipApi {
     int (*event_destroy)(void *);
     int (*event_record)(ampli_ctx *, void *);
     int (*event_sync)(void *);
+    int (*pileup_count)(ampli_ctx *, const uint8_t *, const uint64_t *, int64_t, const uint64_t *, int64_t, int32_t, int32_t, int32_t *, uint64_t *);
     // native transport of the multi-GPU merge (RCCL over xGMI, include/amplisolve_hip.h "ampli_comm")
     int (*comm_create)(ampli_ctx *, int32_t, int32_t, const char *, int32_t, ampli_comm **);
     void (*comm_destroy)(ampli_comm *);

@@ -165,6 +165,16 @@ struct VcArgs {
     const ampli_host_shard *shard = nullptr;
     NativeDist native;
 };
+// computeCounts (bam.cpp): one BAM file -> <out_dir>/<name>.PILEUP.ASEQ
+struct CcArgs {
+    std::string vcf, bam, out_dir;
+    int threads = 4, mbq = 20, mrq = 20, mdc = 20; // Execution_examples.md:46 recommends 20-20-20
+    int64_t *stats = nullptr;                      // optional [4]: records, reads kept, bases counted, lines written
+    std::string *error = nullptr;
+};
+int run_compute_counts(const CcArgs &a);
+// BGZF + BAM structure only (no GPU): stats[4] = alignment records, uncompressed bytes, references, malformed records
+void bam_scan(const std::string &bam, int n_threads, int64_t stats[4]);
 int run_error_estimation(const EeArgs &a);
 int run_variant_calling(const VcArgs &a);
 // ---- annotate.cpp ----

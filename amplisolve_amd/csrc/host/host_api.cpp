@@ -197,6 +197,31 @@ extern "C" int ampli_host_run_variant_calling_sharded(const char *error_file, co
     return run_variant_calling(a);
 }
 
+extern "C" int ampli_host_compute_counts(const char *vcf, const char *bam, const char *out_dir, int32_t threads, int32_t mbq, int32_t mrq, int32_t mdc,
+                                         int64_t *stats)
+{
+    if (!vcf || !bam || !out_dir) { g_err = "vcf, bam and out_dir are required"; return AMPLI_E_INVALID; }
+    CcArgs a;
+    a.vcf = vcf; a.bam = bam; a.out_dir = out_dir; a.threads = threads; a.mbq = mbq; a.mrq = mrq; a.mdc = mdc; a.stats = stats;
+    std::string err;
+    a.error = &err;
+    const int rc = run_compute_counts(a);
+    if (rc) g_err = err;
+    return rc;
+}
+
+extern "C" int ampli_host_bam_scan(const char *bam, int32_t threads, int64_t *stats)
+{
+    if (!bam || !stats) { g_err = "bam and stats are required"; return AMPLI_E_INVALID; }
+    try {
+        bam_scan(bam, threads, stats);
+        return 0;
+    } catch (const Error &e) {
+        g_err = e.msg;
+        return e.code ? e.code : -1;
+    }
+}
+
 extern "C" double ampli_host_fisher(int a, int b, int c, int d) { return fisher_two_sided(a, b, c, d); }
 
 extern "C" double ampli_host_guard_score(int32_t k, int32_t rd, float err, int32_t *ge5, int32_t *lt20)

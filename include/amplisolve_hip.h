@@ -406,6 +406,19 @@ int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int32_t n_sampl
                      int32_t first_sample, uint64_t seed, int32_t depth, int32_t tumour);
 int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t seed);
 
+/*
+ * Upstream of the path: alignments -> per-position counts, i.e. what ASEQ's PILEUP mode / the reference's binary-only
+ * computeCounts produce (/root/reference/Execution_examples.md:16-46: vcf= bam= mbq= mrq= mdc=).  d_bam: the UNCOMPRESSED BAM
+ * alignment records (the host inflates the BGZF blocks); d_rec_off[i]: byte offset of record i's block_size field, every listed
+ * record lying completely inside d_bam with a CIGAR that matches its l_seq (the host checks); d_keys[P]: the panel's unique
+ * positions as (BAM reference id << 32 | 1-based position), ascending.  d_counts int32 [P][8] = {A,C,G,T, Ars,Crs,Grs,Trs} is
+ * ACCUMULATED into (zero it first; batches of one file add up).  Kept reads: mapped, not secondary / QC-fail / duplicate,
+ * MAPQ >= mrq; counted bases: M / = / X columns, A/C/G/T, base quality >= mbq.  d_stats (optional, 2 words, accumulated):
+ * reads kept, bases counted.
+ */
+int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_rec_off, int64_t n_reads, const uint64_t *d_keys, int64_t P,
+                       int32_t mbq, int32_t mrq, int32_t *d_counts, uint64_t *d_stats);
+
 /* tuning knobs.  reduce_sample_splits: 0 = automatic.  reduce_general: 0 = the fast error_reduce kernel
  * (valid while every strand depth is < 2^22; it raises AMPLI_FLAG_RERUN_GENERAL otherwise), 1 = the literal
  * kernel that follows the reference operation by operation for any depth (slower).  reduce_lane_groups: lane

@@ -127,6 +127,16 @@ int ampli_host_run_error_estimation_sharded(const char *panel_design, const char
 int ampli_host_run_variant_calling_sharded(const char *error_file, const char *tumour_dir, const char *output_dir,
                                            const char *coverage_cutoff, const char *p_value, const ampli_host_shard *shard);
 
+/* ---- upstream of the two programs: BAM -> <out_dir>/<bam name without .bam>.PILEUP.ASEQ, i.e. computeCounts / ASEQ PILEUP mode
+ * (/root/reference/Execution_examples.md:16-46: vcf= bam= threads= mbq= mrq= mdc= out=; the reference ships it as a binary without
+ * source, so parity is unpinned -- DESIGN.md).  The host inflates the BGZF blocks (threads), the device decodes the alignment
+ * records and counts (ampli_pileup_count); needs libamplisolve_hip.so + a GPU.  stats (optional) [4]: alignment records, reads
+ * kept, bases counted, lines written. */
+int ampli_host_compute_counts(const char *vcf, const char *bam, const char *out_dir, int32_t threads, int32_t mbq, int32_t mrq, int32_t mdc,
+                              int64_t *stats);
+/* the container only (no GPU): stats[4] = alignment records, uncompressed bytes, reference sequences, malformed records */
+int ampli_host_bam_scan(const char *bam, int32_t threads, int64_t *stats);
+
 /* the decision guard of the variant-calling command line for calls within 1e-6 of a gate (AMPLI_CALL_BORDERLINE): Q by the
  * reference's own operation sequence (VC:3834-3884: double kf_gammaq, long double log10); *ge5 / *lt20 = the comparisons of
  * VC:898 / VC:1023 made in long double */

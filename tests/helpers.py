@@ -75,3 +75,83 @@ def borderline_triples(want=12, seed=5, gate=5.0, eps=1e-6, errs=(0.000001, 0.00
             if abs(q - gate) <= eps and (k, rd, err) not in [(a, b, c) for a, b, c, _ in out]:
                 out.append((k, rd, err, q))
     return out
+
+
+# ---- BAM files for the pileup step (computeCounts): a minimal writer, BGZF framing included ----
+def write_bam(path, refs, reads, rng=None, max_block=60000, level=6):
+    """refs: [(name, length)]; reads: dicts with ref_id, pos (0-based), mapq, flag, cigar [(op char, len)], seq (str), qual (list),
+    optional name.  The stream is cut into BGZF blocks of random sizes (records span block boundaries)."""
+    import struct
+    import zlib
+
+    ops = "MIDNSHP=X"
+    codes = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    text = b"@HD\tVN:1.6\tSO:coordinate\n" + b"".join(f"@SQ\tSN:{n}\tLN:{l}\n".encode() for n, l in refs)
+    raw = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
+    for n, l in refs:
+        raw += struct.pack("<i", len(n) + 1) + n.encode() + b"\0" + struct.pack("<i", l)
+    for k, r in enumerate(reads):
+        name = (r.get("name") or f"r{k}").encode() + b"\0"
+        seq = r["seq"]
+        packed = bytearray((len(seq) + 1) // 2)
+        for i, c in enumerate(seq):
+            packed[i >> 1] |= codes[c] << (4 if i % 2 == 0 else 0)
+        cig = b"".join(struct.pack("<I", (n << 4) | ops.index(op)) for op, n in r["cigar"])
+        body = struct.pack("<iiBBHHHiiii", r["ref_id"], r["pos"], len(name), r["mapq"], 4680, len(r["cigar"]), r["flag"], len(seq), -1, -1, 0)
+        body += name + cig + bytes(packed) + bytes(r["qual"])
+        raw += struct.pack("<i", len(body)) + body
+    out = bytearray()
+    o = 0
+    while o < len(raw):
+        n = min(len(raw) - o, int(rng.integers(1, max_block)) if rng is not None else max_block)
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        data = co.compress(bytes(raw[o:o + n])) + co.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(data) + 25) + data
+        out += struct.pack("<II", zlib.crc32(bytes(raw[o:o + n])) & 0xffffffff, n)
+        o += n
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")  # the EOF marker block
+    open(path, "wb").write(bytes(out))
+    return len(raw)
+
+
+def random_amplicon_reads(rng, refs, amplicons, n_reads, read_len=(60, 140)):
+    """Reads in the style of amplicon sequencing: every read of an amplicon starts near its start; soft clips, insertions,
+    deletions, reverse strands, filtered flags, low qualities and N bases are all drawn."""
+    reads = []
+    for _ in range(n_reads):
+        ref_id, start, end = amplicons[int(rng.integers(len(amplicons)))]
+        pos = max(0, start - 1 + int(rng.integers(-5, 6)))
+        target = int(rng.integers(*read_len))
+        cigar, used = [], 0
+        if rng.random() < 0.3:
+            cigar.append(("S", int(rng.integers(1, 8))))
+        while used < target:
+            n = int(rng.integers(5, 60))
+            cigar.append(("M" if rng.random() < 0.9 else ("=" if rng.random() < 0.5 else "X"), n))
+            used += n
+            u = rng.random()
+            if u < 0.10:
+                cigar.append(("I", int(rng.integers(1, 4))))
+            elif u < 0.20:
+                cigar.append(("D", int(rng.integers(1, 6))))
+            elif u < 0.23:
+                cigar.append(("N", int(rng.integers(10, 40))))
+        if cigar[-1][0] in "IDN":
+            cigar.append(("M", 3))
+        if rng.random() < 0.3:
+            cigar.append(("S", int(rng.integers(1, 8))))
+        if rng.random() < 0.1:
+            cigar.append(("H", 5))
+        qlen = sum(n for op, n in cigar if op in "MIS=X")
+        seq = "".join(rng.choice(list("ACGT"), size=qlen))
+        if rng.random() < 0.2:
+            i = int(rng.integers(qlen))
+            seq = seq[:i] + rng.choice(["N", "R", "M"]) + seq[i + 1:]
+        flag = 0x10 if rng.random() < 0.5 else 0
+        for bit, pr in ((0x4, 0.02), (0x100, 0.03), (0x200, 0.02), (0x400, 0.05), (0x800, 0.03), (0x1, 0.3)):
+            if rng.random() < pr:
+                flag |= bit
+        reads.append(dict(ref_id=ref_id if rng.random() > 0.01 else -1, pos=pos, mapq=int(rng.choice([0, 5, 19, 20, 21, 40, 60])), flag=flag, cigar=cigar, seq=seq,
+                          qual=[int(x) for x in rng.choice([2, 10, 19, 20, 21, 30, 40], size=qlen)]))
+    reads.sort(key=lambda r: (r["ref_id"] if r["ref_id"] >= 0 else 1 << 30, r["pos"]))
+    return reads
