@@ -341,6 +341,10 @@ def main():
     dev_index = local_rank % max(ndev, 1)  # == local_rank on a full node; ranks share a device only in rehearsals
     torch.cuda.set_device(dev_index)
     if multi:
+        if world == 1 and "RANK" not in os.environ:  # --force-dist without a launcher: a process group of one
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29811")
+            os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = "0", "1", "0"
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
