@@ -183,3 +183,86 @@ def test_native_shard_without_rank_zero_fails_loudly(tmp_path):
                        timeout=120, env=env)
     assert r.returncode == 1
     assert "timed out waiting for rank 0's id file" in r.stdout
+
+
+# ---- the native mode with SEVERAL ranks on one GPU: RCCL refuses that, so a shared-memory test double of the few RCCL entry points
+# the HIP library binds (tests/fake_rccl/fake_rccl.cpp, AMPLISOLVE_RCCL_LIB) stands in for the wire.  What this checks is everything
+# around the wire: NativeShard's buffers, counts and chunk order, the id-file rendezvous between real processes, shard 0 as the
+# writer, the row-count prefix of the Summary, empty shards.
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    so = tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so"
+    r = subprocess.run(["hipcc", "-O1", "-fPIC", "-shared", "-std=c++17", "-o", str(so), os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp"), "-lrt"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return str(so)
+
+
+def native_run(world, exe, args, out, fake, env=None):
+    os.makedirs(out, exist_ok=True)
+    procs = []
+    for k in range(world):
+        e = dict(os.environ, AMPLISOLVE_WORLD_SIZE=str(world), AMPLISOLVE_RANK=str(k), AMPLISOLVE_DEVICE="0", AMPLISOLVE_RCCL_LIB=fake,
+                 AMPLISOLVE_ID_FILE=os.path.join(str(out), "rendezvous.id"), AMPLISOLVE_RCCL_TIMEOUT="120", **(env or {}))
+        procs.append(subprocess.Popen([f"{BIN}/{exe}"] + args + [f"output_dir={out}"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n=====\n".join(o[-2000:] for o in outs)
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_native_mode_several_ranks_error_estimation(tmp_path, fake_rccl, world):
+    d = f"{G}/toy_subset"
+    out = tmp_path / "native"
+    outs = native_run(world, "AmpliSolveErrorEstimation", [f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL", "C_value=0.002",
+                                                           "coverage_cutoff=100", "default_error=0.01"], out, fake_rccl, env={"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"})
+    assert (out / "positionSpecificNoise_0.0020.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0020.txt").read()
+    assert all(f"shard {k + 1}/{world}" in outs[k] for k in range(world))
+    assert not os.path.exists(out / "rendezvous.id")
+
+
+def test_native_mode_edge_cases_and_empty_shards(tmp_path, fake_rccl):
+    """the synthetic edge-case panel at cov 1 over 3 ranks, and 2 normal files over 4 ranks (two shards hold no file)"""
+    d = f"{G}/mini_edge"
+    out = tmp_path / "edge"
+    native_run(3, "AmpliSolveErrorEstimation", [f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL", "C_value=0.0005",
+                                                "coverage_cutoff=1", "default_error=0.01"], out, fake_rccl, env={"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"})
+    assert (out / "positionSpecificNoise_0.0005.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0005_cov1.txt").read()
+    d = f"{G}/toy_subset"
+    nd = tmp_path / "N2"
+    nd.mkdir()
+    for n in sorted(os.listdir(f"{d}/NORMAL"))[:2]:
+        os.symlink(f"{d}/NORMAL/{n}", nd / n)
+    args = [f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={nd}", "C_value=0.002", "coverage_cutoff=100", "default_error=0.01"]
+    env = {"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"}
+    one = tmp_path / "one"
+    r = subprocess.run([f"{BIN}/AmpliSolveErrorEstimation"] + args + [f"output_dir={one}"], capture_output=True, text=True, env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1", **env))
+    assert r.returncode == 0, r.stdout + r.stderr
+    native_run(4, "AmpliSolveErrorEstimation", args, tmp_path / "four", fake_rccl, env=env)
+    assert (tmp_path / "four" / "positionSpecificNoise_0.0020.txt").read_text() == (one / "positionSpecificNoise_0.0020.txt").read_text()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_mode_several_ranks_variant_calling(tmp_path, fake_rccl, world):
+    d = f"{G}/toy_subset"
+    table = f"{d}/expected_positionSpecificNoise_0.0020.txt"
+    one = tmp_path / "one"
+    r = subprocess.run([f"{BIN}/AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={d}/TUMOUR", f"output_dir={one}", "coverage_cutoff=100", "p_value=0.05"],
+                       capture_output=True, text=True, env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = tmp_path / "native"
+    os.makedirs(out)
+    procs = []
+    for k in range(world):
+        e = dict(os.environ, AMPLISOLVE_WORLD_SIZE=str(world), AMPLISOLVE_RANK=str(k), AMPLISOLVE_DEVICE="0", AMPLISOLVE_RCCL_LIB=fake_rccl,
+                 AMPLISOLVE_ID_FILE=str(out / "rendezvous.id"))
+        procs.append(subprocess.Popen([f"{BIN}/AmpliSolveVariantCalling", f"errorFile={table}", f"tumour_dir={d}/TUMOUR", f"output_dir={out}", "coverage_cutoff=100",
+                                       "p_value=0.05"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n=====\n".join(o[-2000:] for o in outs)
+    assert (out / "Summary_Variant_Info.txt").read_text() == (one / "Summary_Variant_Info.txt").read_text()
+    vcfs = sorted(n for n in os.listdir(one) if n.endswith(".vcf"))
+    assert vcfs == sorted(n for n in os.listdir(out) if n.endswith(".vcf"))
+    for n in vcfs:
+        assert strip_dates((out / n).read_text()) == strip_dates((one / n).read_text())
+    assert not [n for n in os.listdir(out) if ".part" in n]
