@@ -1588,13 +1588,17 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < AMPLI_CALL_SHARDS) next_queue_n[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
     // blockIdx.x = queue shard, blockIdx.y = workgroup within the shard: one load tells a workgroup what is its to do
     const unsigned shard = blockIdx.x;
+    const int slot = threadIdx.x >> 1, strand = threadIdx.x & 1;
+    // the first pass's item is fetched BEFORE the shard's count is known (the slot exists whatever the count is): the kernel is one
+    // chain of dependent latencies -- count, item, scorer, returning atomic -- and this takes one link out of it
+    const long long i0 = (long long)blockIdx.y * IPB + slot;
+    PcItem first = queue[(size_t)shard * queue_per_shard + (i0 < queue_per_shard ? i0 : 0)];
     long long cnt = (long long)queue_n[shard * AMPLI_CALL_COUNTER_STRIDE];
     if (cnt > queue_per_shard) cnt = queue_per_shard;
-    const int slot = threadIdx.x >> 1, strand = threadIdx.x & 1;
     for (long long ib = (long long)blockIdx.y * IPB; ib < cnt; ib += (long long)gridDim.y * IPB) {
         const long long i = ib + slot;
         const bool on = i < cnt;
-        PcItem it = queue[(size_t)shard * queue_per_shard + (on ? i : ib)];
+        PcItem it = ib == (long long)blockIdx.y * IPB ? first : queue[(size_t)shard * queue_per_shard + (on ? i : ib)];
         const int k = strand ? it.k_bw : it.k_fw;
         const int d = strand ? it.BW : it.rd - it.BW; // VC:895-896
         const float err = strand ? it.e_bw : it.e_fw;

@@ -66,10 +66,11 @@ def back_to_back(reps=40):
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 print(f"calls per launch {n_base}; algorithmic bytes {BYTES / 1e6:.1f} MB", flush=True)
 for rows in ([int(x) for x in os.environ["SWEEP_ROWS"].split(",")] if os.environ.get("SWEEP_ROWS") else [4, 8, 24] if quick else [2, 3, 4, 5, 6, 8, 12, 16, 24]):
-    ctx.set_poisson_tuning(rows, 0)
+  for drain in ([int(x) for x in os.environ["SWEEP_DRAIN"].split(",")] if os.environ.get("SWEEP_DRAIN") else [0]):
+    ctx.set_poisson_tuning(rows, drain)
     red, pc = in_loop()
     bb = back_to_back()
     ok = torch.equal(res["call_mask"], base_mask) and ctx.n_calls_total(res) == n_base
-    print(f"rows/wave {rows:3d}: in the loop {pc:6.1f} us = {BYTES / pc / 1e6:5.2f} TB/s = {BYTES / pc / 1e6 / 8:5.3f} of peak   "
+    print(f"rows/wave {rows:3d} drain blocks/shard {drain:3d}: in the loop {pc:6.1f} us = {BYTES / pc / 1e6:5.2f} TB/s = {BYTES / pc / 1e6 / 8:5.3f} of peak   "
           f"(back to back {bb:6.1f} us; error_estimate beside it {red:6.1f} us)   same={ok}", flush=True)
 ctx.set_poisson_tuning()
