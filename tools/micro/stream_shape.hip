@@ -154,7 +154,7 @@ template <int RB, int DEPTH, int WORK, int OCC, bool RING = false> void run(cons
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char **argv)
 {
     const int S = 256;
     const long long Pmax = 262144;
@@ -166,6 +166,20 @@ int main()
         std::vector<unsigned> h(1 << 22);
         for (size_t i = 0; i < h.size(); ++i) h[i] = (unsigned)(i * 2654435761u) ^ (unsigned)(i >> 7);
         for (size_t o = 0; o < bytes; o += h.size() * 4) hipMemcpy(d + o, h.data(), std::min(h.size() * 4, bytes - o), hipMemcpyHostToDevice);
+    }
+    if (argc > 1 && atoi(argv[1]) == 96) { // poisson_stream's shape: 96 tumour rows, 24 per wave, every wave resident at once
+        const long long P = 100000;
+        run<24, 1, 0, 4>(d, P, 96, d_out, "S=96 ");
+        run<24, 1, 0, 8>(d, P, 96, d_out, "S=96 ");
+        run<24, 2, 0, 8>(d, P, 96, d_out, "S=96 ");
+        run<24, 4, 0, 8>(d, P, 96, d_out, "S=96 ");
+        run<24, 1, 32, 8>(d, P, 96, d_out, "S=96 ");
+        run<24, 1, 64, 8>(d, P, 96, d_out, "S=96 ");
+        run<24, 4, 32, 8>(d, P, 96, d_out, "S=96 ");
+        run<24, 1, 0, 8>(d, P, 256, d_out, "S=256");
+        run<24, 1, 32, 8>(d, P, 256, d_out, "S=256");
+        hipFree(d); hipFree(d_out);
+        return 0;
     }
     for (int pass = 0; pass < 3; ++pass) {
         if (pass == 1) { hipMemset(d, 1, bytes); printf("-- constant data (every byte 1)\n"); }
