@@ -189,8 +189,8 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                 "what": "reference AmpliSolveErrorEstimation.cpp compiled -O2 where it lies (oracle/_ref/ee_ref_driver: storeGermlineStatistics + "
                         "estimateThresholds + generateFinalOutput; its per-position samtools step is not on the path and is left out)",
                 "extrapolated_full_cohort_s": ref["seconds"] * (n_rec / ref["records"]) if ref_dir != "N" else None,
-                "extrapolation": "linear in the number of records; the reference's insert phase is mildly super-linear in the number of samples "
-                                 "(SURVEY section 6), so this is a lower bound on its time" if ref_dir != "N" else None,
+                "extrapolation": "linear in the number of records; the one full-size run of the reference (profiles/r02/bench_cpu_baseline_full.json) took "
+                                 "112.5 s, so the rule errs on the reference's side by 15-30 %" if ref_dir != "N" else None,
             }
             res["error_estimation"]["speedup_vs_reference_records_per_s"] = res["error_estimation"]["records_per_s"] / ref["records_per_s"]
         return res
@@ -267,8 +267,8 @@ def cpu_baseline(cfg, thr, ref_code, full=False):
                       sample=f"{n_ref} of the {S} normal files of the workload ({P} positions each), reference AmpliSolveErrorEstimation.cpp -O2, "
                              "samtools step left out",
                       extrapolated_whole_cohort_s=r["seconds"] * S / n_ref,
-                      extrapolation="seconds x (normals / files timed): linear in records; the reference is mildly super-linear in the number "
-                                    "of samples (SURVEY section 6), so a lower bound")
+                      extrapolation="seconds x (normals / files timed): linear in records; the one full-size run (--cpu-baseline-full, "
+                                    "profiles/r02/bench_cpu_baseline_full.json) took 112.5 s, so the rule errs on the reference's side by ~15 %")
     finally:
         import shutil
 
