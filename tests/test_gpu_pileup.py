@@ -90,3 +90,30 @@ def test_pileup_count_entry_point_checks_its_arguments():
         assert ctx.lib.ampli_pileup_count(ctx.h, None, None, 1, None, 1, 20, 20, None, None) != 0
     finally:
         ctx.close()
+
+
+def test_unsorted_reads_long_reads_and_an_empty_file(tmp_path):
+    """The LDS window of the counting kernel assumes nothing: reads in random order (every update outside the window of its
+    workgroup goes to the global counters), a read whose match run is longer than the window, and a BAM with a header and no
+    alignment at all."""
+    rng = np.random.default_rng(12)
+    reads = helpers.random_amplicon_reads(rng, REFS, AMPS, 3000)
+    reads.append(dict(ref_id=0, pos=900, mapq=60, flag=0, cigar=[("M", 1500)], seq="".join(rng.choice(list("ACGT"), size=1500)), qual=[40] * 1500))
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    helpers.write_bam(tmp_path / "U.bam", REFS, reads, rng=rng, max_block=30000)
+    lines = _positions(rng) + [("chr1", p, ".", ".", ".") for p in range(1231, 2400)]
+    _write_vcf(tmp_path / "v.txt", lines)
+    r = subprocess.run([f"{BIN}/computeCounts", f"vcf={tmp_path}/v.txt", f"bam={tmp_path}/U.bam", "mbq=20", "mrq=20", "mdc=1", f"out={tmp_path}"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    refs, recs = po.read_bam(tmp_path / "U.bam")
+    want = po.aseq_text(lines, po.pileup(refs, recs, [(c, p) for c, p, *_ in lines], 20, 20), 1)
+    assert (tmp_path / "U.PILEUP.ASEQ").read_text() == want
+    helpers.write_bam(tmp_path / "E.bam", REFS, [])
+    r = subprocess.run([f"{BIN}/computeCounts", f"vcf={tmp_path}/v.txt", f"bam={tmp_path}/E.bam", "mdc=0", f"out={tmp_path}"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = (tmp_path / "E.PILEUP.ASEQ").read_text().splitlines()
+    assert len(got) == 1 + len(lines) and all(l.split("\t")[6:] == ["0"] * 9 for l in got[1:])  # mdc = 0: every listed position, all zeros
+    r = subprocess.run([f"{BIN}/computeCounts", f"vcf={tmp_path}/v.txt", f"bam={tmp_path}/missing.bam", f"out={tmp_path}"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "cannot open" in r.stdout
