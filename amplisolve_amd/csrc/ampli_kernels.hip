@@ -1486,6 +1486,7 @@ __global__ __launch_bounds__(256, 8) void poisson_stream_kernel(
     // The call mask starts as "no call" (the drain ORs bits in).  Every wave of the grid clears an equal, CONTIGUOUS share
     // of the mask's bytes -- whole 128-byte lines, one store instruction per 256 bytes -- rather than the 64 scattered
     // bytes per row that belong to its own records (partial-line writes cost the streaming kernel ~10 % in the loop).
+    // (Clearing when a wave leaves instead of when it starts was measured: no faster.)
     {
         const size_t m4 = ((size_t)T * (size_t)R + 3) / 4;       // the mask as dwords (the buffer is padded to a multiple of 4)
         const size_t share = (size_t)rows_per_wave * 16;         // dwords per wave: grid waves x share >= m4
@@ -1505,12 +1506,22 @@ __global__ __launch_bounds__(256, 8) void poisson_stream_kernel(
     if (nt_rows <= 0) return;
     const int ref = valid ? (int)ref_code[p] : 255;
 
+    // where this position's eight thresholds live: the plane-major table, or the block of the position's slice (one
+    // integer division per lane, done once)
+    const float *__restrict__ tbase = thr;
+    long long tstride = P, tp = p;
+    if (thr_L != 0) {
+        const long long k = p / thr_L;
+        tbase = (const float *)((const char *)thr + (size_t)k * thr_bb + (size_t)thr_L * 32);
+        tstride = thr_L;
+        tp = p - k * thr_L;
+    }
     float te[2][4]; // effective error per strand / nucleotide
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
-            te[st][nt] = ampli_effective_err(thr_at(thr, P, thr_L, thr_bb, st * 4 + nt, p)); // VC:887-890
+            te[st][nt] = ampli_effective_err(tbase[(st * 4 + nt) * tstride + tp]); // VC:887-890
         }
     }
     const unsigned shard = blockIdx.x % AMPLI_CALL_SHARDS;
