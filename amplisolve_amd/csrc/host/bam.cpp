@@ -300,6 +300,12 @@ int run_compute_counts(const CcArgs &a)
                 allocs.push_back(p);
                 return p;
             }
+            void release(void *p) // a slot's buffer is replaced by a larger one
+            {
+                if (!p) return;
+                allocs.erase(std::remove(allocs.begin(), allocs.end(), p), allocs.end());
+                check(api->dev_free(ctx, p), "ampli_dev_free");
+            }
         } dev{api};
         int device = 0;
         if (const char *e = getenv("AMPLISOLVE_DEVICE")) device = atoi(e);
@@ -385,9 +391,10 @@ int run_compute_counts(const CcArgs &a)
             carry.assign(hb.p + done, hb.p + n);
             n_records += (int64_t)offs[slot].size();
             if (P > 0 && !offs[slot].empty()) {
-                if (d_bam_cap[slot] < done) { d_bam[slot] = dev.alloc(done + done / 8); d_bam_cap[slot] = done + done / 8; }
+                // (the slot's previous kernel has finished: its event was waited for above)
+                if (d_bam_cap[slot] < done) { dev.release(d_bam[slot]); d_bam[slot] = dev.alloc(done + done / 8); d_bam_cap[slot] = done + done / 8; }
                 const size_t ob = offs[slot].size() * 8;
-                if (d_off_cap[slot] < ob) { d_off[slot] = dev.alloc(ob + ob / 8); d_off_cap[slot] = ob + ob / 8; }
+                if (d_off_cap[slot] < ob) { dev.release(d_off[slot]); d_off[slot] = dev.alloc(ob + ob / 8); d_off_cap[slot] = ob + ob / 8; }
                 dev.check(api->copy_h2d(dev.ctx, d_bam[slot], hb.p, done), "ampli_copy_h2d");
                 dev.check(api->copy_h2d(dev.ctx, d_off[slot], offs[slot].data(), ob), "ampli_copy_h2d");
                 dev.check(api->pileup_count(dev.ctx, (const uint8_t *)d_bam[slot], (const uint64_t *)d_off[slot], (int64_t)offs[slot].size(), d_keys, P,
