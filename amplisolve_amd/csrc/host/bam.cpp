@@ -306,7 +306,7 @@ int run_compute_counts(const CcArgs &a)
                 allocs.erase(std::remove(allocs.begin(), allocs.end(), p), allocs.end());
                 check(api->dev_free(ctx, p), "ampli_dev_free");
             }
-        } dev{api};
+        } dev{api, nullptr, {}};
         int device = 0;
         if (const char *e = getenv("AMPLISOLVE_DEVICE")) device = atoi(e);
         dev.check(api->ctx_create(device, nullptr, &dev.ctx), "ampli_ctx_create");
