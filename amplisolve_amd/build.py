@@ -22,6 +22,8 @@ BIN = os.path.join(PKG, "bin")
 HIP_LIB = os.path.join(LIB, "libamplisolve_hip.so")
 HOST_LIB = os.path.join(LIB, "libamplisolve_host.so")
 
+# ampli_kernels.hip: the path's kernels + their C ABI; ampli_pileup.hip: the upstream counting kernel; ampli_comm.hip: RCCL binding
+HIP_SOURCES = ["ampli_kernels.hip", "ampli_pileup.hip", "ampli_comm.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off"]
 CXX_FLAGS = ["-O2", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-pthread"]
 
@@ -49,11 +51,11 @@ def hipcc_path() -> str:
 
 def build_hip(force: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
-    src = os.path.join(CSRC, "ampli_kernels.hip")
-    deps = [src, os.path.join(CSRC, "ampli_math.h"), os.path.join(CSRC, "ampli_synth.h"),
-            os.path.join(ROOT, "include", "amplisolve_hip.h")]
+    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, "ampli_internal.h"), os.path.join(CSRC, "ampli_math.h"), os.path.join(CSRC, "ampli_synth.h"),
+                   os.path.join(ROOT, "include", "amplisolve_hip.h")]
     if force or _newer(HIP_LIB, deps):
-        _run([hipcc_path(), *HIPCC_FLAGS, "-o", HIP_LIB, src])
+        _run([hipcc_path(), *HIPCC_FLAGS, "-o", HIP_LIB, *srcs])
     return HIP_LIB
 
 

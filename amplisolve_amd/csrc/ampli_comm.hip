@@ -1,0 +1,182 @@
+// amplisolve_amd/csrc/ampli_comm.hip -- ampli_comm_* (include/amplisolve_hip.h): RCCL bound at run time.  No kernels here; the
+// file is compiled with the others so that the collectives share the context's stream and error reporting.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: librccl.so is dlopen'ed by ampli_comm_create, single-GPU runs never load it
+
+#include <dlfcn.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <string>
+
+#include "ampli_internal.h"
+
+// ---------------------------------------------------------------------------
+// Native transport of the multi-GPU merge: RCCL over xGMI, one process per GPU, without Python.  librccl.so is bound at
+// run time (dlopen) the first time a communicator is asked for.  Rendezvous: rank 0 writes the 128-byte ncclUniqueId to
+// a file every rank can see (temporary name + rename, so a reader never sees half of it); the others poll for it.
+// Every collective is enqueued on the context's stream, i.e. ordered with the kernels around it.
+// ---------------------------------------------------------------------------
+struct ampli_comm {
+    ampli_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    int *d_small = nullptr; // 64 int64 words of device scratch for the small collectives
+};
+
+namespace {
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+bool rccl_load(std::string &why)
+{
+    if (g_rccl.h) return true;
+    const char *cands[] = {getenv("AMPLISOLVE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *c : cands) {
+        if (!c) continue;
+        g_rccl.h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+        why = dlerror();
+    }
+    if (!g_rccl.h) return false;
+#define AMPLI_RCCL_BIND(field, sym)                                             \
+    *(void **)(&g_rccl.field) = dlsym(g_rccl.h, sym);                            \
+    if (!g_rccl.field) { why = std::string("librccl: missing ") + sym; g_rccl.h = nullptr; return false; }
+    AMPLI_RCCL_BIND(GetUniqueId, "ncclGetUniqueId") AMPLI_RCCL_BIND(CommInitRank, "ncclCommInitRank") AMPLI_RCCL_BIND(CommDestroy, "ncclCommDestroy")
+    AMPLI_RCCL_BIND(ReduceScatter, "ncclReduceScatter") AMPLI_RCCL_BIND(AllGather, "ncclAllGather") AMPLI_RCCL_BIND(AllReduce, "ncclAllReduce")
+    AMPLI_RCCL_BIND(Send, "ncclSend") AMPLI_RCCL_BIND(Recv, "ncclRecv") AMPLI_RCCL_BIND(GroupStart, "ncclGroupStart") AMPLI_RCCL_BIND(GroupEnd, "ncclGroupEnd")
+    AMPLI_RCCL_BIND(GetErrorString, "ncclGetErrorString")
+#undef AMPLI_RCCL_BIND
+    return true;
+}
+} // namespace
+
+#define RCCL_TRY(c, expr)                                                                                   \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) {                                                                            \
+            (c)->ctx->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r_);                          \
+            return AMPLI_E_HIP;                                                                             \
+        }                                                                                                   \
+    } while (0)
+
+extern "C" int ampli_comm_create(ampli_ctx *ctx, int32_t rank, int32_t world, const char *id_file, int32_t timeout_s, ampli_comm **out)
+{
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || !id_file || !*id_file) return AMPLI_E_INVALID;
+    *out = nullptr;
+    std::string why;
+    if (!rccl_load(why)) return fail(ctx, AMPLI_E_HIP, ("librccl.so could not be loaded: " + why).c_str());
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    const std::string path(id_file), tmp = path + ".tmp" + std::to_string((long)getpid());
+    if (rank == 0) {
+        if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(ctx, AMPLI_E_HIP, "ncclGetUniqueId failed");
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(ctx, AMPLI_E_INVALID, ("cannot write " + tmp).c_str()); }
+        fclose(f);
+        if (rename(tmp.c_str(), path.c_str()) != 0) return fail(ctx, AMPLI_E_INVALID, ("cannot create " + path).c_str());
+    } else {
+        bool got = false;
+        for (int waited_ms = 0; waited_ms <= timeout_s * 1000 && !got; waited_ms += 20) {
+            FILE *f = fopen(path.c_str(), "rb");
+            if (f) {
+                got = fread(&id, 1, sizeof id, f) == sizeof id;
+                fclose(f);
+            }
+            if (!got) usleep(20000);
+        }
+        if (!got) return fail(ctx, AMPLI_E_HIP, ("timed out waiting for rank 0's id file " + path).c_str());
+    }
+    ampli_comm *c = new (std::nothrow) ampli_comm();
+    if (!c) return AMPLI_E_NOMEM;
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) { delete c; return fail(ctx, AMPLI_E_HIP, "ncclCommInitRank failed"); }
+    if (hipMalloc((void **)&c->d_small, 64 * sizeof(long long)) != hipSuccess) { g_rccl.CommDestroy(c->comm); delete c; return AMPLI_E_NOMEM; }
+    *out = c;
+    return AMPLI_OK;
+}
+
+extern "C" void ampli_comm_destroy(ampli_comm *c)
+{
+    if (!c) return;
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->d_small) (void)hipFree(c->d_small);
+    if (c->comm) g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+// sums [world][count] f64 -> this rank's [count] (SUM); xGMI: each rank receives (world-1)/world of count*8 bytes
+extern "C" int ampli_comm_reduce_scatter_f64(ampli_comm *c, const double *d_send, double *d_recv, int64_t count)
+{
+    if (!c || !d_send || !d_recv || count <= 0) return AMPLI_E_INVALID;
+    RCCL_TRY(c, g_rccl.ReduceScatter(d_send, d_recv, (size_t)count, ncclFloat64, ncclSum, c->comm, c->ctx->stream));
+    return AMPLI_OK;
+}
+
+// send [world][count] f32 (chunk k for rank k) -> recv [world][count] (chunk k from rank k): grouped send / recv pairs
+extern "C" int ampli_comm_all_to_all_f32(ampli_comm *c, const float *d_send, float *d_recv, int64_t count)
+{
+    if (!c || !d_send || !d_recv || count <= 0) return AMPLI_E_INVALID;
+    RCCL_TRY(c, g_rccl.GroupStart());
+    for (int k = 0; k < c->world; ++k) {
+        RCCL_TRY(c, g_rccl.Send(d_send + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, c->ctx->stream));
+        RCCL_TRY(c, g_rccl.Recv(d_recv + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, c->ctx->stream));
+    }
+    RCCL_TRY(c, g_rccl.GroupEnd());
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_comm_all_gather_bytes(ampli_comm *c, const void *d_send, void *d_recv, int64_t bytes)
+{
+    if (!c || !d_send || !d_recv || bytes <= 0) return AMPLI_E_INVALID;
+    RCCL_TRY(c, g_rccl.AllGather(d_send, d_recv, (size_t)bytes, ncclUint8, c->comm, c->ctx->stream));
+    return AMPLI_OK;
+}
+
+// host values, in place: element-wise MAX over the ranks (flags travel as one 0/1 word per bit); synchronises
+extern "C" int ampli_comm_all_reduce_max_i32(ampli_comm *c, int32_t *values, int32_t n)
+{
+    if (!c || !values || n < 1 || n > 64) return AMPLI_E_INVALID;
+    HIP_TRY(c->ctx, hipMemcpyAsync(c->d_small, values, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->ctx->stream));
+    RCCL_TRY(c, g_rccl.AllReduce(c->d_small, c->d_small, (size_t)n, ncclInt32, ncclMax, c->comm, c->ctx->stream));
+    HIP_TRY(c->ctx, hipMemcpyAsync(values, c->d_small, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->ctx->stream));
+    HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+    return AMPLI_OK;
+}
+
+// sum of `mine` over the ranks below this one (all-gather of one int64 per rank); synchronises
+extern "C" int ampli_comm_exclusive_sum_i64(ampli_comm *c, int64_t mine, int64_t *before)
+{
+    if (!c || !before || c->world > 63) return AMPLI_E_INVALID;
+    long long *d = (long long *)c->d_small; // word 0: mine; words 1..world: gathered
+    HIP_TRY(c->ctx, hipMemcpyAsync(d, &mine, sizeof(long long), hipMemcpyHostToDevice, c->ctx->stream));
+    RCCL_TRY(c, g_rccl.AllGather(d, d + 1, 1, ncclInt64, c->comm, c->ctx->stream));
+    long long all[64];
+    HIP_TRY(c->ctx, hipMemcpyAsync(all, d + 1, (size_t)c->world * sizeof(long long), hipMemcpyDeviceToHost, c->ctx->stream));
+    HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+    long long s_ = 0;
+    for (int k = 0; k < c->rank; ++k) s_ += all[k];
+    *before = s_;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_comm_barrier(ampli_comm *c)
+{
+    int32_t one = 1;
+    return ampli_comm_all_reduce_max_i32(c, &one, 1);
+}

@@ -1,0 +1,65 @@
+// amplisolve_amd/csrc/ampli_internal.h -- what the translation units of libamplisolve_hip.so share: the context behind
+// ampli_ctx and the error plumbing.  Not part of the ABI (include/amplisolve_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/amplisolve_hip.h"
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct ampli_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    void *ws = nullptr; // workspace for partial accumulator tables
+    size_t ws_bytes = 0;
+    int reduce_splits = 0; // 0 = auto
+    int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
+    int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
+    int grp_size = 1, grp_index = 0; // sliced exchange buffers hold grp_size batches per slice chunk; calls address batch grp_index
+    int rec_layout = 0;     // record layout of every d_recs / d_trecs argument: AMPLI_RECORDS_I32 / _U16 / _U24
+    int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
+    void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
+    size_t queue_items = 0;
+    size_t queue_min_items = 0; // ampli_set_queue_items
+    unsigned long long *queue_n = nullptr; // two counter arrays, used alternately
+    unsigned queue_parity = 0;
+    // optional: the drain kernel of poisson_call on a side stream (ampli_set_async_drain)
+    int async_drain = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_stream_done = nullptr, ev_drain_done = nullptr;
+    bool drain_pending = false;
+    int n_cu = 256;
+    // poisson_call tuning (ampli_set_poisson_tuning; 0 = default)
+    int pc_rows_per_wave = 0, pc_drain_blocks = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            if (ctx) (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
+            return AMPLI_E_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+static inline int fail(ampli_ctx *ctx, int code, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static inline int check_launch(ampli_ctx *ctx, const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        return AMPLI_E_HIP;
+    }
+    return AMPLI_OK;
+}
+

@@ -12,12 +12,10 @@
 //   poisson_stream_kernel<LAY> + poisson_drain_kernel   VC:752-898 (+clones), VC:3721-3884   one record read per (position, tumour)
 //   poisson_call_kernel<MODE,LAY>                  the same evaluated in place (validation mode, dense outputs)
 //   records_pack16_kernel / records_pack24_kernel  int32 records -> the packed layouts
-// See include/amplisolve_hip.h for the data layout and DESIGN.md for the rooflines.
+// See include/amplisolve_hip.h for the data layout and DESIGN.md for the rooflines.  The library's other translation units:
+// ampli_pileup.hip (pileup_count_kernel, the step upstream of the path), ampli_comm.hip (RCCL binding of the multi-GPU merge),
+// ampli_internal.h (the context they share).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h> // types only: librccl.so is dlopen'ed by ampli_comm_create, single-GPU runs never load it
-
-#include <dlfcn.h>
-#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -27,54 +25,9 @@
 #include <string>
 
 #include "../../include/amplisolve_hip.h"
+#include "ampli_internal.h"
 #include "ampli_math.h"
 #include "ampli_synth.h"
-
-// ---------------------------------------------------------------------------
-// context
-// ---------------------------------------------------------------------------
-struct ampli_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err;
-    void *ws = nullptr; // workspace for partial accumulator tables
-    size_t ws_bytes = 0;
-    int reduce_splits = 0; // 0 = auto
-    int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
-    int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
-    int grp_size = 1, grp_index = 0; // sliced exchange buffers hold grp_size batches per slice chunk; calls address batch grp_index
-    int rec_layout = 0;     // record layout of every d_recs / d_trecs argument: AMPLI_RECORDS_I32 / _U16 / _U24
-    int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
-    void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
-    size_t queue_items = 0;
-    size_t queue_min_items = 0; // ampli_set_queue_items
-    unsigned long long *queue_n = nullptr; // two counter arrays, used alternately
-    unsigned queue_parity = 0;
-    // optional: the drain kernel of poisson_call on a side stream (ampli_set_async_drain)
-    int async_drain = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_stream_done = nullptr, ev_drain_done = nullptr;
-    bool drain_pending = false;
-    int n_cu = 256;
-    // poisson_call tuning (ampli_set_poisson_tuning; 0 = default)
-    int pc_rows_per_wave = 0, pc_drain_blocks = 0;
-};
-
-#define HIP_TRY(ctx, expr)                                                                        \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            if (ctx) (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);              \
-            return AMPLI_E_HIP;                                                                   \
-        }                                                                                         \
-    } while (0)
-
-static int fail(ampli_ctx *ctx, int code, const char *msg)
-{
-    if (ctx) ctx->err = msg;
-    return code;
-}
 
 extern "C" int ampli_abi_version(void) { return AMPLI_ABI_VERSION; }
 
@@ -1740,16 +1693,6 @@ __global__ void synth_ref_kernel(unsigned char *ref, const long long P, const un
 // ---------------------------------------------------------------------------
 // host entry points
 // ---------------------------------------------------------------------------
-static int check_launch(ampli_ctx *ctx, const char *what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
-        return AMPLI_E_HIP;
-    }
-    return AMPLI_OK;
-}
-
 static int ensure_ws(ampli_ctx *ctx, size_t bytes)
 {
     if (ctx->ws_bytes >= bytes) return AMPLI_OK;
@@ -2395,363 +2338,4 @@ extern "C" int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, u
     hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_code, (long long)P,
                        (unsigned long long)seed);
     return check_launch(ctx, "synth_ref_kernel");
-}
-
-
-// ---------------------------------------------------------------------------
-// pileup_count: the upstream step of the path, BAM alignments -> per-position base x strand counts (what ASEQ's PILEUP mode
-// / the reference's binary-only computeCounts write as .PILEUP.ASEQ; /root/reference/Execution_examples.md:16-46).
-// The host inflates the BGZF blocks and lists the byte offsets of the alignment records; this kernel decodes the records
-// themselves.  One wave per read at a time, lanes over the bases of a CIGAR match run: the reads of an amplicon start at the
-// same place, so a lane-per-read mapping would have all 64 lanes of a wave add to the SAME counter at every step.
-//   kept reads: mapped, not secondary / QC-fail / duplicate (the pileup engine's default mask), MAPQ >= mrq;
-//   counted bases: inside M / = / X runs (deletions and reference skips contribute nothing), A/C/G/T only, quality >= mbq;
-//   counts[p][0..3] = A,C,G,T over both strands, counts[p][4..7] = the same on the reverse strand (flag 0x10).
-// keys: the panel's unique positions as (BAM reference id << 32 | 1-based position), sorted ascending.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned ld_u32_unaligned(const unsigned char *p)
-{
-    unsigned v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
-
-// A workgroup takes PILEUP_READS consecutive reads (one wave per read at a time, lanes over the bases of a match run) and counts
-// into a private LDS window of PILEUP_WINDOW panel positions that starts where its first read starts: a coordinate-sorted BAM keeps
-// the reads of an amplicon together, so nearly every update is an LDS atomic and the window is flushed with one global atomic per
-// non-zero counter (global atomics straight from the lanes ran at 4 G updates/s -- every read of an amplicon hits the same
-// counters).  Updates outside the window (unsorted files, very long reads) go to the global counters directly.
-constexpr int PILEUP_READS = 256;
-constexpr int PILEUP_WINDOW = 1024;
-
-__global__ __launch_bounds__(256) void pileup_count_kernel(const unsigned char *__restrict__ bam, const unsigned long long *__restrict__ rec_off,
-                                                           const long long n_reads, const unsigned long long *__restrict__ keys, const long long P,
-                                                           const int mbq, const int mrq, int *__restrict__ counts, unsigned long long *__restrict__ stats)
-{
-    __shared__ int win[PILEUP_WINDOW * 8];
-    __shared__ unsigned long long wkeys[PILEUP_WINDOW]; // the window's panel keys: every search of an in-window run stays in LDS
-    __shared__ long long win_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long first = (long long)blockIdx.x * PILEUP_READS;
-    for (int i = threadIdx.x; i < PILEUP_WINDOW * 8; i += 256) win[i] = 0;
-    if (threadIdx.x == 0) { // the window starts at the first panel position at or behind the start of the workgroup's first placed read
-        long long wb = 0;
-        for (long long rd = first; rd < n_reads && rd < first + PILEUP_READS; ++rd) {
-            const unsigned char *r = bam + rec_off[rd] + 4;
-            const int ref_id = (int)ld_u32_unaligned(r), pos = (int)ld_u32_unaligned(r + 4);
-            if (ref_id < 0 || pos < 0) continue;
-            const unsigned long long k0 = ((unsigned long long)(unsigned)ref_id << 32) | (unsigned long long)((long long)pos + 1);
-            long long lo = 0, hi = P;
-            while (lo < hi) {
-                const long long mid = (lo + hi) >> 1;
-                if (keys[mid] < k0) lo = mid + 1;
-                else hi = mid;
-            }
-            wb = lo;
-            break;
-        }
-        win_base = wb;
-    }
-    __syncthreads();
-    const long long wb = win_base;
-    const int nw = (int)(P - wb < PILEUP_WINDOW ? P - wb : PILEUP_WINDOW);
-    for (int i = threadIdx.x; i < nw; i += 256) wkeys[i] = keys[wb + i];
-    __syncthreads();
-    unsigned long long kept = 0, added = 0;
-    unsigned long long prev_k0 = ~0ull; // the reads of an amplicon start at the same place: the last run's search is usually this run's
-    int prev_lo = 0;
-    for (long long read = first + wave; read < n_reads && read < first + PILEUP_READS; read += 4) {
-        const unsigned char *r = bam + rec_off[read] + 4; // past block_size
-        const int ref_id = (int)ld_u32_unaligned(r), pos = (int)ld_u32_unaligned(r + 4);
-        const unsigned bin_mq_nl = ld_u32_unaligned(r + 8), flag_nc = ld_u32_unaligned(r + 12);
-        const int l_read_name = (int)(bin_mq_nl & 0xffu), mapq = (int)((bin_mq_nl >> 8) & 0xffu);
-        const int n_cigar = (int)(flag_nc & 0xffffu);
-        const unsigned flag = flag_nc >> 16;
-        if (ref_id < 0 || pos < 0 || (flag & (0x4u | 0x100u | 0x200u | 0x400u)) != 0 || mapq < mrq) continue;
-        ++kept;
-        const int l_seq = (int)ld_u32_unaligned(r + 16);
-        const unsigned char *cig = r + 32 + l_read_name;
-        const unsigned char *seq = cig + 4 * (size_t)n_cigar;
-        const unsigned char *qual = seq + (l_seq + 1) / 2;
-        const int rev = (int)((flag >> 4) & 1u);
-        long long refpos = pos; // 0-based
-        int qpos = 0;
-        for (int c = 0; c < n_cigar; ++c) {
-            const unsigned op_len = ld_u32_unaligned(cig + 4 * (size_t)c);
-            const unsigned op = op_len & 15u;
-            const int len = (int)(op_len >> 4);
-            if (op == 0 || op == 7 || op == 8) { // M, =, X
-                const unsigned long long k0 = ((unsigned long long)(unsigned)ref_id << 32) | (unsigned long long)(refpos + 1);
-                // the run lies inside the window's key range: everything below happens in LDS
-                const bool inwin = nw > 0 && k0 >= wkeys[0] && k0 + (unsigned long long)len - 1 <= wkeys[nw - 1];
-                if (inwin) {
-                    int lo;
-                    if (k0 == prev_k0) {
-                        lo = prev_lo;
-                    } else { // first window key >= k0 (wave-uniform)
-                        int l = 0, h = nw;
-                        while (l < h) {
-                            const int mid = (l + h) >> 1;
-                            if (wkeys[mid] < k0) l = mid + 1;
-                            else h = mid;
-                        }
-                        lo = l;
-                        prev_k0 = k0;
-                        prev_lo = l;
-                    }
-                    const int wend = lo + len < nw ? lo + len : nw; // the keys of this run are among the next `len`
-                    for (int j = lane; j < len; j += 64) {
-                        const unsigned long long key = k0 + (unsigned long long)j;
-                        int a = lo + j < wend ? lo + j : wend - 1; // no gap in the panel along this run: the key sits at lo + j
-                        if (wkeys[a] != key) {
-                            int b = wend;
-                            a = lo;
-                            while (a < b) {
-                                const int mid = (a + b) >> 1;
-                                if (wkeys[mid] < key) a = mid + 1;
-                                else b = mid;
-                            }
-                        }
-                        if (a < wend && wkeys[a] == key) {
-                            const int q = qpos + j;
-                            const unsigned nib = (seq[q >> 1] >> ((~q & 1) * 4)) & 15u;
-                            const int b4 = nib == 1u ? 0 : (nib == 2u ? 1 : (nib == 4u ? 2 : (nib == 8u ? 3 : -1)));
-                            if (b4 >= 0 && (int)qual[q] >= mbq) {
-                                atomicAdd(&win[a * 8 + b4], 1);
-                                if (rev) atomicAdd(&win[a * 8 + 4 + b4], 1);
-                                ++added;
-                            }
-                        }
-                    }
-                } else {
-                    // outside the window (unsorted file, a run that leaves the window, a position before it): global search and counters
-                    long long lo = 0, hi = P;
-                    while (lo < hi) {
-                        const long long mid = (lo + hi) >> 1;
-                        if (keys[mid] < k0) lo = mid + 1;
-                        else hi = mid;
-                    }
-                    const long long wend = lo + len < P ? lo + len : P;
-                    if (lo < wend && keys[lo] < k0 + (unsigned long long)len) {
-                        for (int j = lane; j < len; j += 64) {
-                            const unsigned long long key = k0 + (unsigned long long)j;
-                            long long a = lo, b = wend;
-                            while (a < b) {
-                                const long long mid = (a + b) >> 1;
-                                if (keys[mid] < key) a = mid + 1;
-                                else b = mid;
-                            }
-                            if (a < wend && keys[a] == key) {
-                                const int q = qpos + j;
-                                const unsigned nib = (seq[q >> 1] >> ((~q & 1) * 4)) & 15u;
-                                const int b4 = nib == 1u ? 0 : (nib == 2u ? 1 : (nib == 4u ? 2 : (nib == 8u ? 3 : -1)));
-                                if (b4 >= 0 && (int)qual[q] >= mbq) {
-                                    atomicAdd(&counts[a * 8 + b4], 1);
-                                    if (rev) atomicAdd(&counts[a * 8 + 4 + b4], 1);
-                                    ++added;
-                                }
-                            }
-                        }
-                    }
-                }
-                refpos += len;
-                qpos += len;
-            } else if (op == 1 || op == 4) { // I, S
-                qpos += len;
-            } else if (op == 2 || op == 3) { // D, N
-                refpos += len;
-            } // H, P: neither
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < PILEUP_WINDOW * 8; i += 256) {
-        const int v = win[i];
-        if (v != 0 && wb + (i >> 3) < P) atomicAdd(&counts[(wb + (i >> 3)) * 8 + (i & 7)], v);
-    }
-    if (stats) {
-        if (lane == 0 && kept) atomicAdd(&stats[0], kept); // reads kept
-        if (added) atomicAdd(&stats[1], added);            // bases counted
-    }
-}
-
-extern "C" int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_rec_off, int64_t n_reads, const uint64_t *d_keys, int64_t P,
-                                  int32_t mbq, int32_t mrq, int32_t *d_counts, uint64_t *d_stats)
-{
-    if (!ctx) return AMPLI_E_INVALID;
-    if (!d_bam || !d_rec_off || n_reads < 0 || !d_keys || P <= 0 || !d_counts) return fail(ctx, AMPLI_E_INVALID, "pileup_count: bad argument");
-    if (n_reads == 0) return AMPLI_OK;
-    if ((n_reads + PILEUP_READS - 1) / PILEUP_READS > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "pileup_count: too many reads in one call; split the batch");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(pileup_count_kernel, dim3((unsigned)((n_reads + PILEUP_READS - 1) / PILEUP_READS)), dim3(256), 0, ctx->stream, (const unsigned char *)d_bam,
-                       (const unsigned long long *)d_rec_off, (long long)n_reads, (const unsigned long long *)d_keys, (long long)P, (int)mbq, (int)mrq,
-                       d_counts, (unsigned long long *)d_stats);
-    return check_launch(ctx, "pileup_count_kernel");
-}
-
-// ---------------------------------------------------------------------------
-// Native transport of the multi-GPU merge: RCCL over xGMI, one process per GPU, without Python.  librccl.so is bound at
-// run time (dlopen) the first time a communicator is asked for.  Rendezvous: rank 0 writes the 128-byte ncclUniqueId to
-// a file every rank can see (temporary name + rename, so a reader never sees half of it); the others poll for it.
-// Every collective is enqueued on the context's stream, i.e. ordered with the kernels around it.
-// ---------------------------------------------------------------------------
-struct ampli_comm {
-    ampli_ctx *ctx = nullptr;
-    ncclComm_t comm = nullptr;
-    int rank = 0, world = 1;
-    int *d_small = nullptr; // 64 int64 words of device scratch for the small collectives
-};
-
-namespace {
-struct RcclApi {
-    void *h = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-};
-RcclApi g_rccl;
-
-bool rccl_load(std::string &why)
-{
-    if (g_rccl.h) return true;
-    const char *cands[] = {getenv("AMPLISOLVE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-    for (const char *c : cands) {
-        if (!c) continue;
-        g_rccl.h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
-        if (g_rccl.h) break;
-        why = dlerror();
-    }
-    if (!g_rccl.h) return false;
-#define AMPLI_RCCL_BIND(field, sym)                                             \
-    *(void **)(&g_rccl.field) = dlsym(g_rccl.h, sym);                            \
-    if (!g_rccl.field) { why = std::string("librccl: missing ") + sym; g_rccl.h = nullptr; return false; }
-    AMPLI_RCCL_BIND(GetUniqueId, "ncclGetUniqueId") AMPLI_RCCL_BIND(CommInitRank, "ncclCommInitRank") AMPLI_RCCL_BIND(CommDestroy, "ncclCommDestroy")
-    AMPLI_RCCL_BIND(ReduceScatter, "ncclReduceScatter") AMPLI_RCCL_BIND(AllGather, "ncclAllGather") AMPLI_RCCL_BIND(AllReduce, "ncclAllReduce")
-    AMPLI_RCCL_BIND(Send, "ncclSend") AMPLI_RCCL_BIND(Recv, "ncclRecv") AMPLI_RCCL_BIND(GroupStart, "ncclGroupStart") AMPLI_RCCL_BIND(GroupEnd, "ncclGroupEnd")
-    AMPLI_RCCL_BIND(GetErrorString, "ncclGetErrorString")
-#undef AMPLI_RCCL_BIND
-    return true;
-}
-} // namespace
-
-#define RCCL_TRY(c, expr)                                                                                   \
-    do {                                                                                                    \
-        ncclResult_t r_ = (expr);                                                                           \
-        if (r_ != ncclSuccess) {                                                                            \
-            (c)->ctx->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r_);                          \
-            return AMPLI_E_HIP;                                                                             \
-        }                                                                                                   \
-    } while (0)
-
-extern "C" int ampli_comm_create(ampli_ctx *ctx, int32_t rank, int32_t world, const char *id_file, int32_t timeout_s, ampli_comm **out)
-{
-    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || !id_file || !*id_file) return AMPLI_E_INVALID;
-    *out = nullptr;
-    std::string why;
-    if (!rccl_load(why)) return fail(ctx, AMPLI_E_HIP, ("librccl.so could not be loaded: " + why).c_str());
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ncclUniqueId id;
-    const std::string path(id_file), tmp = path + ".tmp" + std::to_string((long)getpid());
-    if (rank == 0) {
-        if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(ctx, AMPLI_E_HIP, "ncclGetUniqueId failed");
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(&id, 1, sizeof id, f) != sizeof id) { if (f) fclose(f); return fail(ctx, AMPLI_E_INVALID, ("cannot write " + tmp).c_str()); }
-        fclose(f);
-        if (rename(tmp.c_str(), path.c_str()) != 0) return fail(ctx, AMPLI_E_INVALID, ("cannot create " + path).c_str());
-    } else {
-        bool got = false;
-        for (int waited_ms = 0; waited_ms <= timeout_s * 1000 && !got; waited_ms += 20) {
-            FILE *f = fopen(path.c_str(), "rb");
-            if (f) {
-                got = fread(&id, 1, sizeof id, f) == sizeof id;
-                fclose(f);
-            }
-            if (!got) usleep(20000);
-        }
-        if (!got) return fail(ctx, AMPLI_E_HIP, ("timed out waiting for rank 0's id file " + path).c_str());
-    }
-    ampli_comm *c = new (std::nothrow) ampli_comm();
-    if (!c) return AMPLI_E_NOMEM;
-    c->ctx = ctx; c->rank = rank; c->world = world;
-    if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) { delete c; return fail(ctx, AMPLI_E_HIP, "ncclCommInitRank failed"); }
-    if (hipMalloc((void **)&c->d_small, 64 * sizeof(long long)) != hipSuccess) { g_rccl.CommDestroy(c->comm); delete c; return AMPLI_E_NOMEM; }
-    *out = c;
-    return AMPLI_OK;
-}
-
-extern "C" void ampli_comm_destroy(ampli_comm *c)
-{
-    if (!c) return;
-    (void)hipStreamSynchronize(c->ctx->stream);
-    if (c->d_small) (void)hipFree(c->d_small);
-    if (c->comm) g_rccl.CommDestroy(c->comm);
-    delete c;
-}
-
-// sums [world][count] f64 -> this rank's [count] (SUM); xGMI: each rank receives (world-1)/world of count*8 bytes
-extern "C" int ampli_comm_reduce_scatter_f64(ampli_comm *c, const double *d_send, double *d_recv, int64_t count)
-{
-    if (!c || !d_send || !d_recv || count <= 0) return AMPLI_E_INVALID;
-    RCCL_TRY(c, g_rccl.ReduceScatter(d_send, d_recv, (size_t)count, ncclFloat64, ncclSum, c->comm, c->ctx->stream));
-    return AMPLI_OK;
-}
-
-// send [world][count] f32 (chunk k for rank k) -> recv [world][count] (chunk k from rank k): grouped send / recv pairs
-extern "C" int ampli_comm_all_to_all_f32(ampli_comm *c, const float *d_send, float *d_recv, int64_t count)
-{
-    if (!c || !d_send || !d_recv || count <= 0) return AMPLI_E_INVALID;
-    RCCL_TRY(c, g_rccl.GroupStart());
-    for (int k = 0; k < c->world; ++k) {
-        RCCL_TRY(c, g_rccl.Send(d_send + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, c->ctx->stream));
-        RCCL_TRY(c, g_rccl.Recv(d_recv + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, c->ctx->stream));
-    }
-    RCCL_TRY(c, g_rccl.GroupEnd());
-    return AMPLI_OK;
-}
-
-extern "C" int ampli_comm_all_gather_bytes(ampli_comm *c, const void *d_send, void *d_recv, int64_t bytes)
-{
-    if (!c || !d_send || !d_recv || bytes <= 0) return AMPLI_E_INVALID;
-    RCCL_TRY(c, g_rccl.AllGather(d_send, d_recv, (size_t)bytes, ncclUint8, c->comm, c->ctx->stream));
-    return AMPLI_OK;
-}
-
-// host values, in place: element-wise MAX over the ranks (flags travel as one 0/1 word per bit); synchronises
-extern "C" int ampli_comm_all_reduce_max_i32(ampli_comm *c, int32_t *values, int32_t n)
-{
-    if (!c || !values || n < 1 || n > 64) return AMPLI_E_INVALID;
-    HIP_TRY(c->ctx, hipMemcpyAsync(c->d_small, values, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->ctx->stream));
-    RCCL_TRY(c, g_rccl.AllReduce(c->d_small, c->d_small, (size_t)n, ncclInt32, ncclMax, c->comm, c->ctx->stream));
-    HIP_TRY(c->ctx, hipMemcpyAsync(values, c->d_small, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->ctx->stream));
-    HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
-    return AMPLI_OK;
-}
-
-// sum of `mine` over the ranks below this one (all-gather of one int64 per rank); synchronises
-extern "C" int ampli_comm_exclusive_sum_i64(ampli_comm *c, int64_t mine, int64_t *before)
-{
-    if (!c || !before || c->world > 63) return AMPLI_E_INVALID;
-    long long *d = (long long *)c->d_small; // word 0: mine; words 1..world: gathered
-    HIP_TRY(c->ctx, hipMemcpyAsync(d, &mine, sizeof(long long), hipMemcpyHostToDevice, c->ctx->stream));
-    RCCL_TRY(c, g_rccl.AllGather(d, d + 1, 1, ncclInt64, c->comm, c->ctx->stream));
-    long long all[64];
-    HIP_TRY(c->ctx, hipMemcpyAsync(all, d + 1, (size_t)c->world * sizeof(long long), hipMemcpyDeviceToHost, c->ctx->stream));
-    HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
-    long long s_ = 0;
-    for (int k = 0; k < c->rank; ++k) s_ += all[k];
-    *before = s_;
-    return AMPLI_OK;
-}
-
-extern "C" int ampli_comm_barrier(ampli_comm *c)
-{
-    int32_t one = 1;
-    return ampli_comm_all_reduce_max_i32(c, &one, 1);
 }

@@ -1,0 +1,197 @@
+// amplisolve_amd/csrc/ampli_pileup.hip -- pileup_count_kernel + ampli_pileup_count (include/amplisolve_hip.h): the counting
+// half of computeCounts (BAM -> .PILEUP.ASEQ); the container half is amplisolve_amd/csrc/host/bam.cpp.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ampli_internal.h"
+
+// ---------------------------------------------------------------------------
+// pileup_count: the upstream step of the path, BAM alignments -> per-position base x strand counts (what ASEQ's PILEUP mode
+// / the reference's binary-only computeCounts write as .PILEUP.ASEQ; /root/reference/Execution_examples.md:16-46).
+// The host inflates the BGZF blocks and lists the byte offsets of the alignment records; this kernel decodes the records
+// themselves.  One wave per read at a time, lanes over the bases of a CIGAR match run: the reads of an amplicon start at the
+// same place, so a lane-per-read mapping would have all 64 lanes of a wave add to the SAME counter at every step.
+//   kept reads: mapped, not secondary / QC-fail / duplicate (the pileup engine's default mask), MAPQ >= mrq;
+//   counted bases: inside M / = / X runs (deletions and reference skips contribute nothing), A/C/G/T only, quality >= mbq;
+//   counts[p][0..3] = A,C,G,T over both strands, counts[p][4..7] = the same on the reverse strand (flag 0x10).
+// keys: the panel's unique positions as (BAM reference id << 32 | 1-based position), sorted ascending.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ld_u32_unaligned(const unsigned char *p)
+{
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+
+// A workgroup takes PILEUP_READS consecutive reads (one wave per read at a time, lanes over the bases of a match run) and counts
+// into a private LDS window of PILEUP_WINDOW panel positions that starts where its first read starts: a coordinate-sorted BAM keeps
+// the reads of an amplicon together, so nearly every update is an LDS atomic and the window is flushed with one global atomic per
+// non-zero counter (global atomics straight from the lanes ran at 4 G updates/s -- every read of an amplicon hits the same
+// counters).  Updates outside the window (unsorted files, very long reads) go to the global counters directly.
+constexpr int PILEUP_READS = 256;
+constexpr int PILEUP_WINDOW = 1024;
+
+__global__ __launch_bounds__(256) void pileup_count_kernel(const unsigned char *__restrict__ bam, const unsigned long long *__restrict__ rec_off,
+                                                           const long long n_reads, const unsigned long long *__restrict__ keys, const long long P,
+                                                           const int mbq, const int mrq, int *__restrict__ counts, unsigned long long *__restrict__ stats)
+{
+    __shared__ int win[PILEUP_WINDOW * 8];
+    __shared__ unsigned long long wkeys[PILEUP_WINDOW]; // the window's panel keys: every search of an in-window run stays in LDS
+    __shared__ long long win_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long first = (long long)blockIdx.x * PILEUP_READS;
+    for (int i = threadIdx.x; i < PILEUP_WINDOW * 8; i += 256) win[i] = 0;
+    if (threadIdx.x == 0) { // the window starts at the first panel position at or behind the start of the workgroup's first placed read
+        long long wb = 0;
+        for (long long rd = first; rd < n_reads && rd < first + PILEUP_READS; ++rd) {
+            const unsigned char *r = bam + rec_off[rd] + 4;
+            const int ref_id = (int)ld_u32_unaligned(r), pos = (int)ld_u32_unaligned(r + 4);
+            if (ref_id < 0 || pos < 0) continue;
+            const unsigned long long k0 = ((unsigned long long)(unsigned)ref_id << 32) | (unsigned long long)((long long)pos + 1);
+            long long lo = 0, hi = P;
+            while (lo < hi) {
+                const long long mid = (lo + hi) >> 1;
+                if (keys[mid] < k0) lo = mid + 1;
+                else hi = mid;
+            }
+            wb = lo;
+            break;
+        }
+        win_base = wb;
+    }
+    __syncthreads();
+    const long long wb = win_base;
+    const int nw = (int)(P - wb < PILEUP_WINDOW ? P - wb : PILEUP_WINDOW);
+    for (int i = threadIdx.x; i < nw; i += 256) wkeys[i] = keys[wb + i];
+    __syncthreads();
+    unsigned long long kept = 0, added = 0;
+    unsigned long long prev_k0 = ~0ull; // the reads of an amplicon start at the same place: the last run's search is usually this run's
+    int prev_lo = 0;
+    for (long long read = first + wave; read < n_reads && read < first + PILEUP_READS; read += 4) {
+        const unsigned char *r = bam + rec_off[read] + 4; // past block_size
+        const int ref_id = (int)ld_u32_unaligned(r), pos = (int)ld_u32_unaligned(r + 4);
+        const unsigned bin_mq_nl = ld_u32_unaligned(r + 8), flag_nc = ld_u32_unaligned(r + 12);
+        const int l_read_name = (int)(bin_mq_nl & 0xffu), mapq = (int)((bin_mq_nl >> 8) & 0xffu);
+        const int n_cigar = (int)(flag_nc & 0xffffu);
+        const unsigned flag = flag_nc >> 16;
+        if (ref_id < 0 || pos < 0 || (flag & (0x4u | 0x100u | 0x200u | 0x400u)) != 0 || mapq < mrq) continue;
+        ++kept;
+        const int l_seq = (int)ld_u32_unaligned(r + 16);
+        const unsigned char *cig = r + 32 + l_read_name;
+        const unsigned char *seq = cig + 4 * (size_t)n_cigar;
+        const unsigned char *qual = seq + (l_seq + 1) / 2;
+        const int rev = (int)((flag >> 4) & 1u);
+        long long refpos = pos; // 0-based
+        int qpos = 0;
+        for (int c = 0; c < n_cigar; ++c) {
+            const unsigned op_len = ld_u32_unaligned(cig + 4 * (size_t)c);
+            const unsigned op = op_len & 15u;
+            const int len = (int)(op_len >> 4);
+            if (op == 0 || op == 7 || op == 8) { // M, =, X
+                const unsigned long long k0 = ((unsigned long long)(unsigned)ref_id << 32) | (unsigned long long)(refpos + 1);
+                // the run lies inside the window's key range: everything below happens in LDS
+                const bool inwin = nw > 0 && k0 >= wkeys[0] && k0 + (unsigned long long)len - 1 <= wkeys[nw - 1];
+                if (inwin) {
+                    int lo;
+                    if (k0 == prev_k0) {
+                        lo = prev_lo;
+                    } else { // first window key >= k0 (wave-uniform)
+                        int l = 0, h = nw;
+                        while (l < h) {
+                            const int mid = (l + h) >> 1;
+                            if (wkeys[mid] < k0) l = mid + 1;
+                            else h = mid;
+                        }
+                        lo = l;
+                        prev_k0 = k0;
+                        prev_lo = l;
+                    }
+                    const int wend = lo + len < nw ? lo + len : nw; // the keys of this run are among the next `len`
+                    for (int j = lane; j < len; j += 64) {
+                        const unsigned long long key = k0 + (unsigned long long)j;
+                        int a = lo + j < wend ? lo + j : wend - 1; // no gap in the panel along this run: the key sits at lo + j
+                        if (wkeys[a] != key) {
+                            int b = wend;
+                            a = lo;
+                            while (a < b) {
+                                const int mid = (a + b) >> 1;
+                                if (wkeys[mid] < key) a = mid + 1;
+                                else b = mid;
+                            }
+                        }
+                        if (a < wend && wkeys[a] == key) {
+                            const int q = qpos + j;
+                            const unsigned nib = (seq[q >> 1] >> ((~q & 1) * 4)) & 15u;
+                            const int b4 = nib == 1u ? 0 : (nib == 2u ? 1 : (nib == 4u ? 2 : (nib == 8u ? 3 : -1)));
+                            if (b4 >= 0 && (int)qual[q] >= mbq) {
+                                atomicAdd(&win[a * 8 + b4], 1);
+                                if (rev) atomicAdd(&win[a * 8 + 4 + b4], 1);
+                                ++added;
+                            }
+                        }
+                    }
+                } else {
+                    // outside the window (unsorted file, a run that leaves the window, a position before it): global search and counters
+                    long long lo = 0, hi = P;
+                    while (lo < hi) {
+                        const long long mid = (lo + hi) >> 1;
+                        if (keys[mid] < k0) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    const long long wend = lo + len < P ? lo + len : P;
+                    if (lo < wend && keys[lo] < k0 + (unsigned long long)len) {
+                        for (int j = lane; j < len; j += 64) {
+                            const unsigned long long key = k0 + (unsigned long long)j;
+                            long long a = lo, b = wend;
+                            while (a < b) {
+                                const long long mid = (a + b) >> 1;
+                                if (keys[mid] < key) a = mid + 1;
+                                else b = mid;
+                            }
+                            if (a < wend && keys[a] == key) {
+                                const int q = qpos + j;
+                                const unsigned nib = (seq[q >> 1] >> ((~q & 1) * 4)) & 15u;
+                                const int b4 = nib == 1u ? 0 : (nib == 2u ? 1 : (nib == 4u ? 2 : (nib == 8u ? 3 : -1)));
+                                if (b4 >= 0 && (int)qual[q] >= mbq) {
+                                    atomicAdd(&counts[a * 8 + b4], 1);
+                                    if (rev) atomicAdd(&counts[a * 8 + 4 + b4], 1);
+                                    ++added;
+                                }
+                            }
+                        }
+                    }
+                }
+                refpos += len;
+                qpos += len;
+            } else if (op == 1 || op == 4) { // I, S
+                qpos += len;
+            } else if (op == 2 || op == 3) { // D, N
+                refpos += len;
+            } // H, P: neither
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PILEUP_WINDOW * 8; i += 256) {
+        const int v = win[i];
+        if (v != 0 && wb + (i >> 3) < P) atomicAdd(&counts[(wb + (i >> 3)) * 8 + (i & 7)], v);
+    }
+    if (stats) {
+        if (lane == 0 && kept) atomicAdd(&stats[0], kept); // reads kept
+        if (added) atomicAdd(&stats[1], added);            // bases counted
+    }
+}
+
+extern "C" int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_rec_off, int64_t n_reads, const uint64_t *d_keys, int64_t P,
+                                  int32_t mbq, int32_t mrq, int32_t *d_counts, uint64_t *d_stats)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_bam || !d_rec_off || n_reads < 0 || !d_keys || P <= 0 || !d_counts) return fail(ctx, AMPLI_E_INVALID, "pileup_count: bad argument");
+    if (n_reads == 0) return AMPLI_OK;
+    if ((n_reads + PILEUP_READS - 1) / PILEUP_READS > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "pileup_count: too many reads in one call; split the batch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(pileup_count_kernel, dim3((unsigned)((n_reads + PILEUP_READS - 1) / PILEUP_READS)), dim3(256), 0, ctx->stream, (const unsigned char *)d_bam,
+                       (const unsigned long long *)d_rec_off, (long long)n_reads, (const unsigned long long *)d_keys, (long long)P, (int)mbq, (int)mrq,
+                       d_counts, (unsigned long long *)d_stats);
+    return check_launch(ctx, "pileup_count_kernel");
+}

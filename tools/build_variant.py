@@ -31,8 +31,9 @@ def build(name):
     src = os.path.join(ROOT, "amplisolve_amd", "csrc", f"_variant_{name}.hip")
     open(src, "w").write(text)
     try:
+        others = [os.path.join(ROOT, "amplisolve_amd", "csrc", f) for f in ("ampli_pileup.hip", "ampli_comm.hip")]
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-o",
-                        os.path.join(OUT, f"{name}.so"), src], check=True)
+                        os.path.join(OUT, f"{name}.so"), src, *others], check=True)
     finally:
         os.remove(src)
 
