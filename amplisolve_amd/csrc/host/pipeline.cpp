@@ -16,6 +16,7 @@
 #include <iomanip>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 #include "hip_loader.hpp"
 #include "host.hpp"
@@ -104,6 +105,37 @@ struct DevBuf {
 
 struct DevSlot {
     DevBuf prim, ext, aux, mask, rd, rd_ext;
+};
+
+// The context is opened on a side thread while the main thread reads the panel / the error table: loading the HIP runtime and
+// the code object takes 0.1-0.2 s, a good part of a command line's wall time on small and medium cohorts.
+struct DevAsync {
+    Dev dev;
+    std::thread th;
+    std::exception_ptr ex;
+    bool started = false;
+    void start()
+    {
+        started = true;
+        th = std::thread([this] {
+            try {
+                dev.open();
+            } catch (...) {
+                ex = std::current_exception();
+            }
+        });
+    }
+    Dev &get() // the opened context; rethrows what open() threw (no device, no library: there is no CPU fallback)
+    {
+        if (!started) start();
+        if (th.joinable()) th.join();
+        if (ex) std::rethrow_exception(ex);
+        return dev;
+    }
+    ~DevAsync()
+    {
+        if (th.joinable()) th.join();
+    }
 };
 
 size_t chunk_bytes_setting()
@@ -336,6 +368,8 @@ int run_error_estimation(const EeArgs &a)
         auto hook = [&](int rc, const char *what) {
             if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what + (native.err.empty() ? "" : " -- " + native.err)};
         };
+        DevAsync dev_async;
+        if (!no_germlines) dev_async.start(); // after the native shard (it may pick the device), beside the panel parsing
         const std::string interm = a.output_dir + "/AmpliSolveErrorEstimation_interm_files"; // EE:414
         if (writer) mkdir_p(interm);
         srand((unsigned)time(nullptr));
@@ -375,8 +409,7 @@ int run_error_estimation(const EeArgs &a)
         if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << first_sample + 1 << ".." << first_sample + S << std::endl;
         std::cout << "Running function storeGermlineStatistics:" << std::endl;
 
-        Dev dev;
-        dev.open();
+        Dev &dev = dev_async.get();
         const int64_t P = panel.P();
         float *d_rate = dev.alloc<float>((size_t)P * 8), *d_germ = dev.alloc<float>((size_t)P * 4);
         uint8_t *d_code = dev.alloc<uint8_t>((size_t)P * 4), *d_gp = dev.alloc<uint8_t>((size_t)P * 4);
@@ -546,6 +579,8 @@ int run_variant_calling(const VcArgs &a)
         auto hook = [&](int rc, const char *what) {
             if (rc != 0) throw Error{AMPLI_E_INVALID, std::string("shard hook failed: ") + what + (native.err.empty() ? "" : " -- " + native.err)};
         };
+        DevAsync dev_async;
+        dev_async.start(); // beside the reading of the error table
         const std::string interm = a.output_dir + "/AmpliSolveVariantCalling_interm_files"; // VC:307
         mkdir_p(writer ? interm : a.output_dir);
         const double t0 = now_s();
@@ -574,8 +609,7 @@ int run_variant_calling(const VcArgs &a)
         double parse_s = 0;
         int chunks_done = 0;
         if (T > 0 || !sh) { // a shard of a multi-process run may hold no tumour file
-            Dev dev;
-            dev.open();
+            Dev &dev = dev_async.get();
             float *d_thr = dev.upload(thr.data(), thr.size());
             uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
             unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
