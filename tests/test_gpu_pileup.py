@@ -82,14 +82,9 @@ def test_pileup_counts_feed_the_error_estimation(tmp_path):
     assert len(table) == 1 + len(lines)
 
 
-def test_pileup_count_entry_point_checks_its_arguments():
-    from amplisolve_amd import Context
-
-    ctx = Context(0)
-    try:
-        assert ctx.lib.ampli_pileup_count(ctx.h, None, None, 1, None, 1, 20, 20, None, None) != 0
-    finally:
-        ctx.close()
+def test_pileup_count_entry_point_checks_its_arguments(ctx):
+    assert ctx.lib.ampli_pileup_count(ctx.h, None, None, 1, None, 1, 20, 20, None, None) != 0
+    assert b"bad argument" in ctx.lib.ampli_last_error(ctx.h)
 
 
 def test_unsorted_reads_long_reads_and_an_empty_file(tmp_path):
