@@ -392,7 +392,8 @@ int run_compute_counts(const CcArgs &a)
             n_records += (int64_t)offs[slot].size();
             if (P > 0 && !offs[slot].empty()) {
                 // (the slot's previous kernel has finished: its event was waited for above)
-                if (d_bam_cap[slot] < done) { dev.release(d_bam[slot]); d_bam[slot] = dev.alloc(done + done / 8); d_bam_cap[slot] = done + done / 8; }
+                // (+64: the staged kernel copies whole 16-byte pieces, so up to 15 bytes behind the last record are read)
+                if (d_bam_cap[slot] < done + 64) { dev.release(d_bam[slot]); d_bam[slot] = dev.alloc(done + done / 8 + 64); d_bam_cap[slot] = done + done / 8 + 64; }
                 const size_t ob = offs[slot].size() * 8;
                 if (d_off_cap[slot] < ob) { dev.release(d_off[slot]); d_off[slot] = dev.alloc(ob + ob / 8); d_off_cap[slot] = ob + ob / 8; }
                 dev.check(api->copy_h2d(dev.ctx, d_bam[slot], hb.p, done), "ampli_copy_h2d");

@@ -410,7 +410,8 @@ int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, uint64_t see
  * Upstream of the path: alignments -> per-position counts, i.e. what ASEQ's PILEUP mode / the reference's binary-only
  * computeCounts produce (/root/reference/Execution_examples.md:16-46: vcf= bam= mbq= mrq= mdc=).  d_bam: the UNCOMPRESSED BAM
  * alignment records (the host inflates the BGZF blocks); d_rec_off[i]: byte offset of record i's block_size field, every listed
- * record lying completely inside d_bam with a CIGAR that matches its l_seq (the host checks); d_keys[P]: the panel's unique
+ * record lying completely inside d_bam with a CIGAR that matches its l_seq (the host checks), and the buffer readable for 16 bytes
+ * behind the last record (the kernel copies whole 16-byte pieces; d_bam itself 16-byte aligned); d_keys[P]: the panel's unique
  * positions as (BAM reference id << 32 | 1-based position), ascending.  d_counts int32 [P][8] = {A,C,G,T, Ars,Crs,Grs,Trs} is
  * ACCUMULATED into (zero it first; batches of one file add up).  Kept reads: mapped, not secondary / QC-fail / duplicate,
  * MAPQ >= mrq; counted bases: M / = / X columns, A/C/G/T, base quality >= mbq.  d_stats (optional, 2 words, accumulated):

@@ -64,7 +64,7 @@ for threads in (4, 16):
 
 # the kernel alone
 ctx = Context(0)
-d_bam = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+d_bam = torch.frombuffer(bytearray(raw + bytes(64)), dtype=torch.uint8).cuda()  # the kernel copies whole 16-byte pieces
 off = torch.from_numpy(len(header) + np.arange(N, dtype=np.uint64).astype(np.int64) * (rec_len + 4)).cuda()
 keys = torch.from_numpy(np.concatenate([(np.int64(s) + np.arange(L, dtype=np.int64)) for s in amp_start])).cuda()  # ref id 0 << 32 | pos
 counts = torch.zeros((keys.numel(), 8), dtype=torch.int32, device="cuda")
