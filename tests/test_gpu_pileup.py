@@ -112,3 +112,21 @@ def test_unsorted_reads_long_reads_and_an_empty_file(tmp_path):
     assert len(got) == 1 + len(lines) and all(l.split("\t")[6:] == ["0"] * 9 for l in got[1:])  # mdc = 0: every listed position, all zeros
     r = subprocess.run([f"{BIN}/computeCounts", f"vcf={tmp_path}/v.txt", f"bam={tmp_path}/missing.bam", f"out={tmp_path}"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot open" in r.stdout
+
+
+def test_long_reads_take_the_unstaged_walk(tmp_path):
+    """256 consecutive records of 300-500 bp reads do not fit the kernel's 56 KB LDS stage: those groups are walked one wave per
+    read from global memory (the fallback of pileup_count_staged_kernel); same counts."""
+    rng = np.random.default_rng(21)
+    amps = [(0, 1000, 1600), (1, 5000, 5700)]
+    reads = helpers.random_amplicon_reads(rng, REFS, amps, 1200, read_len=(300, 500))
+    helpers.write_bam(tmp_path / "L.bam", REFS, reads, rng=rng)
+    lines = [(REFS[r][0], p, ".", ".", ".") for r, s, e in amps for p in range(s, e + 1)]
+    _write_vcf(tmp_path / "v.txt", lines)
+    r = subprocess.run([f"{BIN}/computeCounts", f"vcf={tmp_path}/v.txt", f"bam={tmp_path}/L.bam", "mbq=20", "mrq=20", "mdc=1", f"out={tmp_path}"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    refs, recs = po.read_bam(tmp_path / "L.bam")
+    assert sum(len(x["seq"]) for x in recs[:256]) > 56 * 1024
+    want = po.aseq_text(lines, po.pileup(refs, recs, [(c, p) for c, p, *_ in lines], 20, 20), 1)
+    assert (tmp_path / "L.PILEUP.ASEQ").read_text() == want
