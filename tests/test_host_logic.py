@@ -116,6 +116,35 @@ def test_error_table_writer_and_reader_cells(tmp_path):
     assert thr[0, 1, 0] == np.float32(0.002189) and thr[1, 2, 0] == np.float32(0.01) and thr[0, 0, 0] == -2.0
 
 
+def test_error_table_io_does_not_depend_on_the_thread_count(tmp_path, monkeypatch):
+    """The table is formatted / tokenised in slices on up to 8 threads: 20 000 rows (duplicated positions included) written and read
+    back with 1 and with 8 threads give the same bytes and the same thresholds."""
+    rng = np.random.default_rng(8)
+    bed = tmp_path / "p.bed"
+    bed.write_text("".join(f"chr{1 + k % 5}\t{1000 * k + 1}\t{1000 * k + 40}\n" for k in range(490)) + "chr1\t20\t60\n")  # the last amplicon overlaps the first
+    refb = tmp_path / "ref.txt"
+    lines = []
+    for k in range(490):
+        lines += [f"chr{1 + k % 5}\t{p}\t{'ACGT'[p % 4]}\n" for p in range(1000 * k + 1, 1000 * k + 41)]
+    lines += [f"chr1\t{p}\t{'ACGT'[p % 4]}\n" for p in range(20, 61)]
+    refb.write_text("".join(lines))
+    co = HostCohort(str(bed), refbases_file=str(refb))
+    P = co.P
+    rate = rng.random((2, 4, P)).astype(np.float32) * np.float32(0.01)
+    code = (rng.random((4, P)) < 0.1).astype(np.uint8)
+    gval = rng.random((4, P)).astype(np.float32)
+    gpres = (rng.random((4, P)) < 0.5).astype(np.uint8)
+    outs, thrs = [], []
+    for n in ("1", "8"):
+        monkeypatch.setenv("AMPLISOLVE_THREADS", n)
+        out = tmp_path / f"t{n}.txt"
+        co.write_error_table(rate, code, gval, gpres, str(out))
+        outs.append(out.read_bytes())
+        thrs.append(read_error_table(str(out))[1])
+    assert outs[0] == outs[1] and outs[0].count(b"\n") == 1 + 490 * 40 + 41
+    assert np.array_equal(thrs[0].view(np.int32), thrs[1].view(np.int32))
+
+
 def test_fisher_matches_scipy():
     scipy = pytest.importorskip("scipy.stats")
     H = host_lib()
