@@ -682,8 +682,6 @@ def test_packed_shard_path_equals_single_pass(ctx, shards, S):
 def test_hipgraph_capture_replays_the_same_pass():
     """A whole pass (error_estimate -> poisson_call) captured into a hipGraph on the context's own stream and
     replayed gives the same table, mask and calls as the eager pass (small, launch-bound panel)."""
-    import time
-
     import torch
 
     from amplisolve_amd import Context
@@ -719,20 +717,7 @@ def test_hipgraph_capture_replays_the_same_pass():
     assert torch.equal(res["call_mask"], eager_mask) and torch.equal(fin.thr, eager_thr)
     calls = g_ctx.read_calls(res)
     assert len(calls) == len(eager_calls) > 0 and np.array_equal(calls["record"], eager_calls["record"])
-    # launch-bound shape: replaying the graph must not be slower than enqueueing the four kernels one by one
-    n = 200
-    t0 = time.perf_counter()
-    for _ in range(n):
-        one_pass()
-    g_ctx.sync()
-    t_eager = (time.perf_counter() - t0) / n
-    t0 = time.perf_counter()
-    for _ in range(n):
-        g_ctx.graph_launch(graph)
-    g_ctx.sync()
-    t_graph = (time.perf_counter() - t0) / n
-    print(f"config-2 pass: eager {t_eager*1e6:.1f} us, hipGraph replay {t_graph*1e6:.1f} us")
-    assert t_graph < 1.5 * t_eager
+    # (how long a replay takes next to the eager enqueue is a measurement, not a correctness property: tools/graph_timing.py)
     g_ctx.graph_destroy(graph)
     g_ctx.close()
 

@@ -20,6 +20,9 @@ for name, rb in [(n, {"u24": 24, "i32": 32, "u16": 16}[n]) for n in (sys.argv[1:
     n, _ = ctx.pack(normals, name)
     t, _ = ctx.pack(tumours, name)
     ctx.set_record_layout(name)
+    # RB_SPLITS / RB_ROWS / RB_DRAIN: ampli_set_tuning / ampli_set_poisson_tuning knobs for A/B runs (0 = automatic)
+    ctx.set_tuning(int(os.environ.get("RB_SPLITS", "0")))
+    ctx.set_poisson_tuning(int(os.environ.get("RB_ROWS", "0")), int(os.environ.get("RB_DRAIN", "0")))
     fin = ctx.error_estimate(n, P, 0.002, 100)
     res = ctx.poisson_call(t, P, fin.thr, ref_code, 100, capacity=1 << 20)
     reps = 30
@@ -37,7 +40,7 @@ for name, rb in [(n, {"u24": 24, "i32": 32, "u16": 16}[n]) for n in (sys.argv[1:
     red = sorted(ctx.elapsed_ms(e[0], e[1]) for e in evs)
     pc = sorted(ctx.elapsed_ms(e[1], e[2]) for e in evs)
     b = rb * P * S + 88 * P
-    print(f"{name}: error_estimate median {red[reps // 2] * 1e3:6.1f} us (min {red[0] * 1e3:6.1f}) = {b / red[reps // 2] / 1e9:5.2f} TB/s = {b / red[reps // 2] / 1e9 / 8:5.3f} of peak;"
+    print(f"{os.environ.get('RB_TAG', '')} {name}: error_estimate median {red[reps // 2] * 1e3:6.1f} us (min {red[0] * 1e3:6.1f}) = {b / red[reps // 2] / 1e9:5.2f} TB/s = {b / red[reps // 2] / 1e9 / 8:5.3f} of peak;"
           f"  poisson_call median {pc[reps // 2] * 1e3:6.1f} us;  flags {ctx.flags()}", flush=True)
     ctx.close()
     del n, t, fin, res
