@@ -379,7 +379,11 @@ int ampli_graph_destroy(void *graph_exec);
 /*
  * Native transport of the multi-GPU merge (one process per GPU, no Python): RCCL over xGMI, bound at run time
  * (librccl.so is only loaded when a communicator is created).  Rendezvous through a file every rank can see: rank 0
- * writes its ncclUniqueId there, the others wait up to timeout_s for it.  Collectives are enqueued on the context's
+ * removes whatever file of that name a dead run left behind and writes its ncclUniqueId there, tagged with the world size,
+ * the launch's AMPLISOLVE_JOB_NONCE (optional; any integer the launcher gives every rank) and the time; the others wait up
+ * to timeout_s for a file that carries THEIR world size and nonce and is not older than the job, and ncclCommInitRank
+ * itself is bounded by timeout_s as well (RCCL has no timeout of its own): a missing rank or a stale file ends in
+ * AMPLI_E_HIP with a message, never in a hang.  Collectives are enqueued on the context's
  * stream; the *_i32 / *_i64 helpers take HOST values and synchronise.  Buffer shapes as in "Position-sliced merge".
  */
 typedef struct ampli_comm ampli_comm;

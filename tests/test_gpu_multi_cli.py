@@ -266,3 +266,87 @@ def test_native_mode_several_ranks_variant_calling(tmp_path, fake_rccl, world):
     for n in vcfs:
         assert strip_dates((out / n).read_text()) == strip_dates((one / n).read_text())
     assert not [n for n in os.listdir(out) if ".part" in n]
+
+
+def _write_id_file(path, world, nonce=0, age_s=0, magic=b"AMPLRCC2"):
+    """an id file as ampli_comm_create writes it (csrc/ampli_comm.hip, struct IdFile) with a dead communicator id"""
+    import struct
+    import time
+
+    with open(path, "wb") as f:
+        f.write(magic + struct.pack("<iiQq", world, 0, nonce, int(time.time()) - age_s) + b"/fake_rccl_dead_run".ljust(128, b"\0"))
+
+
+def test_stale_id_file_is_ignored_and_the_job_runs(tmp_path, fake_rccl):
+    """A run that died left its id file behind (old time stamp, dead id).  Round 2 let ranks > 0 read it on their first poll and
+    wait in ncclCommInitRank for ever; now rank 0 replaces it and the readers do not accept what is older than the job."""
+    d = f"{G}/toy_subset"
+    out = tmp_path / "native"
+    os.makedirs(out)
+    _write_id_file(out / "rendezvous.id", world=2, age_s=3600)
+    native_run(2, "AmpliSolveErrorEstimation", [f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL", "C_value=0.002",
+                                                "coverage_cutoff=100", "default_error=0.01"], out, fake_rccl, env={"AMPLISOLVE_REFBASES_FILE": f"{d}/refbases.txt"})
+    assert (out / "positionSpecificNoise_0.0020.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0020.txt").read()
+
+
+@pytest.mark.parametrize("case", ["fresh_dead_id", "other_world", "other_nonce", "old_format"])
+def test_id_file_of_another_job_fails_loudly_not_for_ever(tmp_path, fake_rccl, case):
+    """Rank 1 of 2 alone with an id file that is not its job's.  A file of another world size, another launch (nonce) or
+    another format is rejected by name; one that looks right but whose communicator is dead gets as far as
+    ncclCommInitRank, which is bounded by the same timeout.  Either way: exit status 1 within seconds, a message saying why."""
+    import time
+
+    d = f"{G}/toy_subset"
+    out = tmp_path / "o"
+    os.makedirs(out)
+    idf = out / "rendezvous.id"
+    env = dict(os.environ, AMPLISOLVE_WORLD_SIZE="2", AMPLISOLVE_RANK="1", AMPLISOLVE_RCCL_TIMEOUT="3", AMPLISOLVE_DEVICE="0",
+               AMPLISOLVE_RCCL_LIB=fake_rccl, AMPLISOLVE_ID_FILE=str(idf), AMPLISOLVE_REFBASES_FILE=f"{d}/refbases.txt", AMPLISOLVE_JOB_NONCE="77")
+    if case == "fresh_dead_id":
+        _write_id_file(idf, world=2, nonce=77)
+        expect = "ncclCommInitRank did not complete within 3 s"
+    elif case == "other_world":
+        _write_id_file(idf, world=4, nonce=77)
+        expect = "written for 4 ranks, this job has 2"
+    elif case == "other_nonce":
+        _write_id_file(idf, world=2, nonce=78)
+        expect = "belongs to another launch"
+    else:
+        open(idf, "wb").write(b"/fake_rccl_dead_run".ljust(128, b"\0"))  # the bare 128-byte id of round 2
+        expect = "not an id file of this library version"
+    t0 = time.time()
+    r = subprocess.run([f"{BIN}/AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
+                        "C_value=0.002", "coverage_cutoff=100", "default_error=0.01", f"output_dir={out}"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    try:
+        assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
+        assert expect in r.stdout, r.stdout[-2000:]
+        assert time.time() - t0 < 60
+    finally:
+        if os.path.exists("/dev/shm/fake_rccl_dead_run"):  # the test double's segment for the dead id
+            os.unlink("/dev/shm/fake_rccl_dead_run")
+
+
+def test_native_launcher_ends_the_job_when_one_shard_fails(tmp_path, fake_rccl):
+    """tools/launch_native.sh: shard 1 cannot read one of its files and exits 1 before its first collective; the other ranks are
+    already inside theirs (RCCL -- and the test double -- would wait for ever).  The launcher must stop them and return 1
+    promptly instead of waiting for every pid in turn."""
+    import shutil
+    import time
+
+    d = f"{G}/toy_subset"
+    nd = tmp_path / "N"
+    shutil.copytree(f"{d}/NORMAL", nd)
+    names = sorted(os.listdir(nd))
+    os.remove(nd / names[-1])
+    os.symlink("/nonexistent/target.PILEUP.ASEQ", nd / names[-1])  # listed by the directory scan, unreadable for the shard that owns it
+    env = dict(os.environ, AMPLISOLVE_RCCL_LIB=fake_rccl, AMPLISOLVE_DEVICE="0", AMPLISOLVE_RCCL_TIMEOUT="60", AMPLISOLVE_REFBASES_FILE=f"{d}/refbases.txt",
+               TMPDIR=str(tmp_path))
+    t0 = time.time()
+    r = subprocess.run([os.path.join(ROOT, "tools", "launch_native.sh"), "3", "AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa",
+                        f"germline_dir={nd}", "C_value=0.002", "coverage_cutoff=100", "default_error=0.01", f"output_dir={tmp_path}/o"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 1, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "stopping the others" in r.stderr
+    assert time.time() - t0 < 120
+    assert not [n for n in os.listdir(tmp_path) if n.startswith("amplisolve_rccl_id.")]
