@@ -134,7 +134,8 @@ struct FileResult {
     std::vector<Extra> extras;
     std::vector<Irregular> irregular; // .sample is filled in by the caller; .record holds the POSITION here
     int64_t n_lines = 0, n_off = 0, n_irregular = 0, n_malformed = 0;
-    bool needs_i32 = false; // a count above 2^24 - 2: the chunk has to be packed as int32
+    bool overflows = false; // a count that the layout being packed cannot hold: the chunk is packed again, wider
+    int64_t max_count = 0;  // largest strand count of the file (decides how wide)
     std::string error;
     int error_code = 0;
 };
@@ -244,7 +245,8 @@ void parse_file(const Panel &panel, const std::string &path, int layout, char *d
                         if (w[j] < 0 || w[j] > INT32_MAX)
                             return bail(path + ": data line " + std::to_string(line_idx + 1) +
                                         ": a strand count is negative (reverse count above the total) or beyond int32");
-                        if (w[j] > max_count) out.needs_i32 = true;
+                        if (w[j] > out.max_count) out.max_count = w[j];
+                        if (w[j] > max_count) out.overflows = true;
                         rec[j] = (int32_t)w[j];
                     }
                     const uint32_t k = occ[pi]++;
@@ -254,7 +256,7 @@ void parse_file(const Panel &panel, const std::string &path, int layout, char *d
                         out.irregular.push_back(Irregular{0u, (uint32_t)pi, k, (int32_t)RD});
                     }
                     if (k == 0) {
-                        if (!out.needs_i32) put_record(layout, dst + (size_t)pi * rb, rec);
+                        if (!out.overflows) put_record(layout, dst + (size_t)pi * rb, rec);
                         if (line) line[(size_t)pi] = line_idx;
                     } else {
                         Extra e;
@@ -307,6 +309,8 @@ struct ChunkStream::Impl {
     int n_threads = 1;
     bool keep_line = false;
     int per_chunk = 1, n_chunks = 0;
+    int floor_layout = AMPLI_RECORDS_U16; // narrowest layout the packer may use (AMPLISOLVE_RECORDS)
+    int start_layout = AMPLI_RECORDS_U16; // layout the next chunk is packed in first
     std::vector<std::unique_ptr<Chunk>> slots;
     std::mutex mu;
     std::condition_variable cv;
@@ -325,11 +329,25 @@ struct ChunkStream::Impl {
         c.index = ci; c.first = lo; c.n = n; c.P = P; c.last = ci == n_chunks - 1;
         c.n_lines = c.n_offpanel = c.n_irregular = c.n_malformed = 0;
         c.irregular.clear();
-        int layout = AMPLI_RECORDS_U24;
+        // The narrowest layout the chunk's counts fit (identical results in all three; the kernels' time follows the bytes):
+        // 8 x uint16 = 16 B up to 65534 reads per strand and base, 8 x 24 bit = 24 B up to 2^24 - 2, else int32.  A chunk is
+        // packed optimistically in the layout the previous one needed and packed again, wider, if a count does not fit --
+        // at most once, because the first pass has seen the largest count.
+        int layout = start_layout;
+        int64_t mx = 0; // largest strand count of the chunk
+        auto width = [](int lay) { return lay == AMPLI_RECORDS_U16 ? 0 : (lay == AMPLI_RECORDS_U24 ? 1 : 2); };
+        auto needed = [](int64_t m) { return m <= 65534 ? AMPLI_RECORDS_U16 : (m <= 0xFFFFFE ? AMPLI_RECORDS_U24 : AMPLI_RECORDS_I32); };
         std::vector<FileResult> res;
         for (int attempt = 0; attempt < 2; ++attempt) {
             res.assign((size_t)n, FileResult());
             const size_t rb = record_bytes(layout);
+            if ((size_t)n * (size_t)P * rb > c.prim_cap) { // the buffers are sized for the narrowest layout; a wider chunk grows its own
+                host_free(c.prim, c.prim_pinned);
+                c.prim = nullptr;
+                c.prim_cap = (size_t)per_chunk * (size_t)P * rb;
+                c.prim = host_alloc(c.prim_cap, c.prim_pinned);
+                if (!c.prim) throw Error{AMPLI_E_NOMEM, "cannot allocate the record buffers"};
+            }
             if (keep_line) c.line_prim.assign((size_t)n * P, -1);
             std::atomic<int> next{0};
             auto work = [&] {
@@ -343,15 +361,20 @@ struct ChunkStream::Impl {
             work();
             for (auto &t : th) t.join();
             bool widen = false;
+            mx = 0;
             for (auto &r : res) {
                 if (!r.error.empty()) throw Error{r.error_code ? r.error_code : AMPLI_E_INVALID, r.error};
-                widen |= r.needs_i32;
+                widen |= r.overflows;
+                mx = std::max(mx, r.max_count);
             }
             if (!widen) break;
             if (layout == AMPLI_RECORDS_I32) throw Error{AMPLI_E_RANGE, "count beyond int32"};
-            layout = AMPLI_RECORDS_I32; // a count above 2^24 - 2 somewhere in the chunk: pack it again as int32
+            layout = needed(mx);
         }
         c.layout = layout;
+        // the next chunk starts in what THIS one needed (never narrower than AMPLISOLVE_RECORDS allows): a deep cohort is not
+        // parsed twice per chunk, and one outlier widens its own chunk and at most the next
+        start_layout = width(needed(mx)) < width(floor_layout) ? floor_layout : needed(mx);
         // extras of this chunk: slots for the largest multiplicity any of ITS files shows at a position
         std::vector<uint32_t> mult((size_t)P, 0);
         bool any_extra = false;
@@ -441,11 +464,17 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
     if (n_threads <= 0) n_threads = std::min(16, (int)std::thread::hardware_concurrency());
     im->n_threads = std::max(1, n_threads);
     im->keep_line = keep_line_no;
+    if (const char *e = getenv("AMPLISOLVE_RECORDS")) { // narrowest record layout the packer may use: u16 (default) | u24 | i32
+        const std::string v(e);
+        if (v == "u24") im->floor_layout = im->start_layout = AMPLI_RECORDS_U24;
+        else if (v == "i32") im->floor_layout = im->start_layout = AMPLI_RECORDS_I32;
+        else if (v != "u16" && v != "auto" && !v.empty()) throw Error{AMPLI_E_INVALID, "AMPLISOLVE_RECORDS must be u16, u24 or i32"};
+    }
     const int64_t P = panel.P();
     const int S = (int)im->files.size();
-    // samples per chunk: about chunk_bytes of 24-byte records, at least one sample, and not so few that the parser
-    // threads idle
-    int per = (int)std::max<int64_t>(1, (int64_t)(chunk_bytes / (size_t)std::max<int64_t>(1, P * 24)));
+    // samples per chunk: about chunk_bytes of records in the narrowest layout allowed, at least one sample, and not so few
+    // that the parser threads idle
+    int per = (int)std::max<int64_t>(1, (int64_t)(chunk_bytes / (size_t)std::max<int64_t>(1, P * (int64_t)record_bytes(im->start_layout))));
     per = std::max(per, std::min(S, im->n_threads));
     per = std::min(per, std::max(1, S));
     im->per_chunk = per;
@@ -454,7 +483,7 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
     for (int i = 0; i < n_slots; ++i) {
         std::unique_ptr<Chunk> c(new Chunk());
         c->slot = i;
-        c->prim_cap = (size_t)per * (size_t)P * 32; // room for the int32 layout
+        c->prim_cap = (size_t)per * (size_t)P * record_bytes(im->start_layout); // a chunk that needs wider records grows its buffer (fill)
         c->prim = host_alloc(c->prim_cap, c->prim_pinned);
         if (!c->prim) throw Error{AMPLI_E_NOMEM, "cannot allocate the record buffers"};
         im->slots.push_back(std::move(c));

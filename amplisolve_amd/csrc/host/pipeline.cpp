@@ -140,7 +140,7 @@ struct DevAsync {
 
 size_t chunk_bytes_setting()
 {
-    // about this many bytes of 24-byte records per chunk (AMPLISOLVE_CHUNK_MB); three chunks are in flight
+    // about this many bytes of records (in the narrowest layout) per chunk (AMPLISOLVE_CHUNK_MB); three chunks are in flight
     size_t mb = 128;
     if (const char *e = getenv("AMPLISOLVE_CHUNK_MB")) mb = (size_t)std::max(1, atoi(e));
     if (const char *e = getenv("AMPLISOLVE_CHUNK_BYTES")) return (size_t)std::max(1ll, atoll(e)); // tests: down to one sample per chunk
@@ -424,7 +424,7 @@ int run_error_estimation(const EeArgs &a)
         struct EvGuard { const HipApi *api; void *ev; ~EvGuard() { if (ev) api->event_destroy(ev); } } evg{dev.api, ev};
         DevSlot dslots[3];
         int64_t n_lines = 0;
-        double parse_s = 0, wait_s = 0;
+        double parse_s = 0, wait_s = 0, rec_bytes_up = 0;
         int chunks_done = 0;
         // The cohort streams through in chunks of samples: while chunk k is uploaded and reduced into the table, the
         // parser threads are already packing chunks k+1, k+2 into the other pinned buffers.  A depth beyond the fast
@@ -433,6 +433,7 @@ int run_error_estimation(const EeArgs &a)
         for (int attempt = 0; attempt < 2; ++attempt) {
             chunks_done = 0;
             n_lines = 0;
+            rec_bytes_up = 0;
             if (S > 0) {
                 ChunkStream cs(panel, files, threads, false, chunk_bytes_setting(), 3);
                 for (Chunk *c; (c = cs.next()) != nullptr;) {
@@ -448,6 +449,7 @@ int run_error_estimation(const EeArgs &a)
                     dev.check(dev.api->event_sync(ev), "ampli_event_sync"); // the chunk's buffers are free again
                     wait_s += now_s() - w0;
                     n_lines += c->n_lines;
+                    rec_bytes_up += (double)c->n * (double)(P + c->E) * (double)record_bytes(c->layout);
                     ++chunks_done;
                     if ((first_sample + c->first + c->n) / 50 > (first_sample + c->first) / 50)
                         std::cout << "\tParsed successfully " << c->first + c->n << "/" << S << "  samples" << std::endl; // EE:1475-1478
@@ -514,7 +516,7 @@ int run_error_estimation(const EeArgs &a)
         std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING panel " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done
-                      << " parse_busy " << parse_s << " device_wait " << wait_s << "\nTIMING finish " << t3 - t2 << "\nTIMING write " << t4 - t3 << std::endl;
+                      << " parse_busy " << parse_s << " device_wait " << wait_s << " record_MB " << rec_bytes_up / 1e6 << "\nTIMING finish " << t3 - t2 << "\nTIMING write " << t4 - t3 << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;
     } catch (const Error &e) {
@@ -606,7 +608,7 @@ int run_variant_calling(const VcArgs &a)
         const int64_t P = panel.P();
         std::vector<CallRow> rows;
         int64_t n_lines = 0;
-        double parse_s = 0;
+        double parse_s = 0, rec_bytes_up = 0;
         int chunks_done = 0;
         if (T > 0 || !sh) { // a shard of a multi-process run may hold no tumour file
             Dev &dev = dev_async.get();
@@ -675,6 +677,7 @@ int run_variant_calling(const VcArgs &a)
                 if (d_calls) dev.free(d_calls);
                 if (!done) throw Error{AMPLI_E_CAPACITY, "variant calling did not complete a pass: " + why};
                 n_lines += c->n_lines;
+                rec_bytes_up += (double)c->n * (double)(P + c->E) * (double)record_bytes(c->layout);
                 ++chunks_done;
                 cs.release(c);
             }
@@ -800,7 +803,7 @@ int run_variant_calling(const VcArgs &a)
         }
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING table " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done << " parse_busy "
-                      << parse_s << " calls " << rows.size() << " guarded " << n_guarded << " dropped_by_guard " << n_dropped << "\nTIMING annotate+write " << now_s() - t2 << std::endl;
+                      << parse_s << " record_MB " << rec_bytes_up / 1e6 << " calls " << rows.size() << " guarded " << n_guarded << " dropped_by_guard " << n_dropped << "\nTIMING annotate+write " << now_s() - t2 << std::endl;
         std::cout << "\nAmpliSolveVariantCalling execution was successful. The results can be found at : " << summary << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;

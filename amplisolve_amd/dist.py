@@ -214,3 +214,44 @@ class SlicedMerger:
         """The current stream waits for the collectives of `handle`."""
         for h in handle:
             h.wait()
+
+    def bytes_received_per_step(self) -> dict:
+        """What one batch's exchange brings to a rank (the collectives are issued once per `batches` batches, so a round
+        moves `batches` times this): every other rank's contribution to the own slice, every other rank's block."""
+        w, L = self.world, self.L
+        rs, a2a, ag = (w - 1) * 21 * L * 8, (w - 1) * 8 * L * 4, (w - 1) * self.block_bytes
+        return {"reduce_scatter_f64": rs, "all_to_all_f32": a2a, "all_gather_u8": ag, "total": rs + a2a + ag}
+
+    def time_collectives(self, reps: int = 10) -> dict:
+        """Each of the three collectives alone, `reps` rounds back to back on slot 0's buffers, nothing else on the device:
+        mean milliseconds per ROUND (a round serves `batches` batches).  Call outside any pipeline: it overwrites slot 0."""
+        import torch
+        import torch.distributed as dist
+
+        dev = self.sums[0].device
+        out = {}
+        for name, start in (("exchange(reduce_scatter_f64+all_to_all_f32)", lambda: self.start_exchange(0)), ("all_gather_u8", lambda: self.start_gather(0))):
+            self.wait(start())
+            torch.cuda.synchronize(dev)
+            dist.barrier(self.group)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                self.wait(start())
+            b.record()
+            torch.cuda.synchronize(dev)
+            out[name] = a.elapsed_time(b) / reps
+        if self.native:
+            for name, fn in (("reduce_scatter_f64", lambda: dist.reduce_scatter_tensor(self.sum_slice[0], self.sums[0], op=dist.ReduceOp.SUM, group=self.group)),
+                             ("all_to_all_f32", lambda: dist.all_to_all_single(self.gm_recv[0], self.gm[0], group=self.group))):
+                fn()
+                torch.cuda.synchronize(dev)
+                dist.barrier(self.group)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(reps):
+                    fn()
+                b.record()
+                torch.cuda.synchronize(dev)
+                out[name] = a.elapsed_time(b) / reps
+        return out

@@ -60,8 +60,9 @@ def parse_args():
     ap.add_argument("--records", default="auto", choices=["auto", "i32", "u24", "u16"],
                     help="record layout resident in HBM (identical results): i32 = 8 x int32 = 32 B per record; u24 = 8 x 24 bits = "
                          "24 B (counts <= 2^24 - 2, i.e. everything the fast kernels accept); u16 = 8 x uint16 = 16 B (counts <= 65534). "
-                         "auto (default) = u24 when the cohort fits, else i32.  The cohort is packed once at setup "
-                         "(ampli_records_pack24/16); at N = 1 the other layouts are timed too, outside the timed region")
+                         "auto (default) = the narrowest the workload's counts fit -- what the command lines' host packer uploads for the "
+                         "same cohort (csrc/host/aseq.cpp).  The cohort is packed once at setup (ampli_records_pack24/16); at N = 1 the "
+                         "other layouts are timed too, outside the timed region")
     ap.add_argument("--merge", default="sliced", choices=["sliced", "allreduce"],
                     help="N>1 exchange: sliced = reduce-scatter + all-to-all + all-gather by position slices (default); "
                          "allreduce = one packed all-reduce + all-gather of whole germ-max regions")
@@ -72,6 +73,8 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: run the N>1 code path (process group, merge, pipelined loop) "
                     "even with one rank -- over RCCL this exercises the real collectives on a one-GPU box")
     ap.add_argument("--check", action="store_true", help="N>1: verify the merged table against a single-pass reduction of all shards")
+    ap.add_argument("--no-strong-base", action="store_true", help="N>1, strong scaling: skip the one-GPU timing of the whole job on rank 0 "
+                    "(strong_base / efficiency in the line)")
     return ap.parse_args()
 
 
@@ -160,7 +163,8 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
         res = {
             "workload": cfg["name"], "text_bytes": w["normal_text_bytes"] + w["tumour_text_bytes"], "files": S + T,
             "error_estimation": {"wall_s": ee_wall, "records": n_rec, "records_per_s": n_rec / ee_wall, "text_GB_per_s": w["normal_text_bytes"] / ee_wall / 1e9,
-                                 "record_array_MB": n_rec * 24 / 1e6, "host_peak_rss_MB": ee_rss,
+                                 "record_array_MB": ee_t.get("stream.record_MB"), "bytes_per_record_uploaded": (ee_t.get("stream.record_MB", 0) * 1e6 / max(1, P * S)),
+                                 "host_peak_rss_MB": ee_rss,
                                  "phases_s": {"panel": ee_t.get("panel"), "stream(parse+upload+reduce)": ee_t.get("stream"), "parser_busy": ee_t.get("stream.parse_busy"),
                                               "waiting_for_gpu": ee_t.get("stream.device_wait"), "table_write": ee_t.get("write")},
                                  "chunks": int(ee_t.get("stream.chunks", 0))},
@@ -169,7 +173,8 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                                 "phases_s": {"table_read": vc_t.get("table"), "stream(parse+upload+call)": vc_t.get("stream"), "parser_busy": vc_t.get("stream.parse_busy"),
                                              "annotate+write": vc_t.get("annotate+write")}},
             "records_per_s": (n_rec + t_rec) / (ee_wall + vc_wall),
-            "note": "wall clock of the two executables incl. process start and HIP runtime start-up (~0.15 s each); record layout uploaded = 24-byte records",
+            "note": "wall clock of the two executables incl. process start and HIP runtime start-up (~0.15 s each); the host packer uploads the "
+                    "narrowest record layout the counts fit (bytes_per_record_uploaded)",
         }
         # the reference's error estimation on the same files (a subset directory of symlinks when the cohort is large)
         ref_dir = "N"
@@ -318,16 +323,50 @@ def kernel_source_sha():
 
 
 # ----------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as fresh child processes (one per
+    GPU, torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process makes any GPU call, pass rank 0's JSON line
+    through, and end with the children's status.  Never falls through to one rank."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in pr.stdout:
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = pr.wait()
+    if rc != 0:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank job ended with status {rc}")
+    if line is None:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank job printed no result line")
+    d = json.loads(line)
+    if d.get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} ranks, the job reports n_gpus = {d.get('n_gpus')}")
+    print(line, flush=True)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)  # no GPU call has been made in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.config is None:
         args.config = "c4" if max(world, args.gpus) > 1 else "c3"
     cfg = CONFIGS[args.config]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the rank count of the line must be the one that ran")
 
     multi = world > 1 or args.force_dist  # the N>1 code path (also runs with one rank under --force-dist)
     import torch
@@ -389,7 +428,8 @@ def main():
         if int(fits.item()):
             packed[name] = (pn, pt)
         del pn, pt
-    layout = args.records if args.records != "auto" else ("u24" if "u24" in packed else "i32")
+    # auto: the narrowest layout the counts fit, which is what the command lines' host packer uploads for this cohort
+    layout = args.records if args.records != "auto" else ("u16" if "u16" in packed else "u24" if "u24" in packed else "i32")
     if layout not in packed:
         raise SystemExit(f"--records {layout}: a count of this workload does not fit that layout")
     normals, tumours = packed[layout]
@@ -685,10 +725,43 @@ def main():
         return ms, (time.perf_counter() - t0_) / reps * 1e3
 
     t_local_ms = None
+    coll_ms, coll_bytes, strong_base = None, None, None
     if multi:
         if fins[0] is None:
             fins[0] = ctx.error_estimate(normals, P, 0.002, 100)
         t_local_ms, _ = timed_passes(local_step, max(10, args.steps))
+        fence()
+        if sliced:  # each collective of the exchange alone (one round serves G batches), nothing else on the devices
+            coll_ms = merger.time_collectives(10)
+            coll_bytes = merger.bytes_received_per_step()
+            fence()
+        if cfg["strong"] and not args.no_strong_base:
+            # The SAME job on ONE GPU, timed by rank 0 while the others wait: the base the driver's 1-GPU run cannot be (that
+            # run is config 3, this job is config 4), so that every N > 1 line carries its own speed-up and efficiency.
+            if rank == 0:
+                del normals, tumours, packed
+                torch.cuda.empty_cache()
+                an = ctx.synth_fill(P, S_total, first_sample=0, seed=SEED, depth=depth)
+                an = ctx.pack(an, layout)[0] if layout != "i32" else an
+                at = ctx.synth_fill(P, T_total, first_sample=0, seed=SEED, depth=depth, tumour=True)
+                at = ctx.pack(at, layout)[0] if layout != "i32" else at
+                mask1 = torch.empty((T_total, P), dtype=torch.uint8, device=ctx.device)
+                f1 = ctx.error_estimate(an, P, 0.002, 100)
+
+                def whole_job():
+                    ctx.error_estimate(an, P, 0.002, 100, out=f1)
+                    ctx.poisson_call(at, P, f1.thr, ref_code, 100, mode=mode, call_mask=mask1, capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
+
+                ms1, _ = timed_passes(whole_job, 10)
+                if ctx.flags(clear=True) != 0:
+                    raise SystemExit("kernel flags raised in the one-GPU base of the strong-scaling job")
+                strong_base = {"n_gpus": 1, "ms_per_step": ms1, "value": (P * S_total + P * T_total) / (ms1 * 1e-3), "passes": 10,
+                               "note": "the whole job (all normals, all tumours of the configuration) on rank 0's GPU alone, after the timed "
+                                       "region, HIP events around 10 passes; same kernels, same record layout"}
+                del an, at, mask1, f1
+                normals = tumours = None
+                packed = {}
+            fence()
     sustained = None
     if not multi and lanes is None and args.sustained > 0:
         # the headline's timed window is a few milliseconds; this is the same pass repeated for ~half a second
@@ -752,17 +825,30 @@ def main():
         # this same command (tools/collect_profiles.sh) and corrected as MI355X_MICROARCH.md prescribes; committed
         # under profiles/.  null when the workload is not the profiled one.
         traffic, traffic_src = None, None
-        pj = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+        pj = os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")
+        if not os.path.exists(pj):
+            pj = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
         if args.config == "c3" and not multi and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
                 if pm.get("kernel_source_sha256") == kernel_source_sha():  # offline counters of exactly these kernels, else nothing
                     traffic = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in pm["kernels"].items()
                                   if any(part in k for part in dom.split("+"))) or None
-                    traffic_src = ("profiles/r02/pmc_summary.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on "
+                    traffic_src = (os.path.relpath(pj, ROOT) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command on "
                                    "this kernel source (sha256 matches), gfx950 x2 read correction; offline, not collected in this run")
             except Exception:
                 traffic = None
+        # the other half of the step gets its own roofline entry (same definitions): algorithmic bytes, HIP-event time, PMC traffic
+        if t_red >= t_call:
+            oth, oth_ms, oth_bytes = f"poisson_stream_kernel<{lay}>+poisson_drain_kernel", t_call, call_bytes
+        else:
+            oth, oth_ms, oth_bytes = f"error_reduce_kernel<true, 1, {lay}>", t_red, red_bytes
+        oth_traffic = None
+        if traffic_src:
+            try:
+                oth_traffic = sum(v.get("hbm_bytes_per_launch", 0.0) for k, v in pm["kernels"].items() if any(part in k for part in oth.split("+"))) or None
+            except Exception:
+                oth_traffic = None
         out = {
             "metric": "position-evaluations/s (error-est + Poisson call)",
             "value": evals / elapsed,
@@ -772,7 +858,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong" if cfg["strong"] else "weak",
+            "scaling": "none" if world == 1 else ("strong" if cfg["strong"] else "weak"),
             "vs_baseline": None,
             "dtype": {"i32": "int32", "u24": "24-bit", "u16": "uint16"}[layout] + " counts; f64 sums / Poisson; f32 rates",
             "data": "synthetic",
@@ -781,10 +867,16 @@ def main():
                        "parallelism": f"tumour+normal sample shards x{world} ({'the fixed job split' if cfg['strong'] else 'one shard of the configuration per GPU'})" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table -- one round of collectives per group of independent batches, three groups in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if multi else ""),
                        "merge": (args.merge if multi else None), "batches_per_exchange": (G if sliced else None),
                        "rehearsal": ("N>1 code path forced on one rank (--force-dist)" if args.force_dist and world == 1 else None),
-                       "records": f"{layout} ({rec_bytes} B per record: 8 fields x {rec_bytes // 8 * 8} bits)"},
+                       "records": f"{layout} ({rec_bytes} B per record: 8 fields x {rec_bytes} bits)",
+                       "records_why": ("--records auto: the narrowest layout this workload's counts fit, which is the layout the command lines' host "
+                                       "packer uploads for the same cohort (csrc/host/aseq.cpp; e2e block: error_estimation.record_array_MB)"
+                                       if args.records == "auto" else "--records given")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
                          "traffic_source": traffic_src},
+            "roofline_other_kernel": {"bound": "hbm", "kernel": oth, "achieved": oth_bytes / (oth_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": oth_bytes / (oth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": oth_traffic, "avg_ms": oth_ms,
+                                      "algorithmic_bytes": oth_bytes},
             "kernels": {"error_reduce_ms": t_red, "error_reduce_GBs": red_bytes / (t_red * 1e-3) / 1e9,
                         "poisson_call_ms": t_call, "poisson_call_GBs": call_bytes / (t_call * 1e-3) / 1e9,
                         "poisson_call_main_stream_ms": t_call_main, "drain": "side stream, overlapped with the next batch" if args.async_drain else "main stream",
@@ -801,9 +893,19 @@ def main():
         if sustained:
             out["sustained"] = sustained
         if multi:
-            out["communication"] = {"local_step_ms": t_local_ms, "exposed_ms_per_step": max(0.0, ms_per_step - t_local_ms),
+            out["communication"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "merge": args.merge,
+                                    "local_step_ms": t_local_ms, "exposed_ms_per_step": max(0.0, ms_per_step - t_local_ms),
+                                    "bytes_received_per_rank_and_step": coll_bytes,
+                                    "collective_ms_per_round": coll_ms, "batches_per_round": (G if sliced else 1),
                                     "note": "local_step = reduce + finalize of the rank's own table + poisson_call with no exchange (rank 0, after the "
-                                            "timed region); exposed = ms_per_step - local_step"}
+                                            "timed region); exposed = ms_per_step - local_step; collective_ms_per_round: each collective alone, 10 rounds "
+                                            "back to back after the timed region (one round serves batches_per_round batches); world_size and backend as "
+                                            "torch.distributed reports them (nccl = RCCL)"}
+            if strong_base:
+                out["strong_base"] = strong_base
+                out["strong_base_value"] = strong_base["value"]
+                out["speedup_vs_one_gpu"] = out["value"] / strong_base["value"]
+                out["efficiency"] = out["value"] / strong_base["value"] / world
         if not multi and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(cfg, fin.thr.cpu().numpy(), ref_code.cpu().numpy(), full=args.cpu_baseline_full)

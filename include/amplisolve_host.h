@@ -76,8 +76,9 @@ int ampli_host_sample_order(const char *dir, char *out, int64_t cap);
 
 /* ---- the cohort as the command lines see it: a stream of chunks of consecutive samples, already in the device record
  * layout (what ampli_records of include/amplisolve_hip.h describes).  The callback gets one chunk at a time, in visit
- * order, while the next ones are being parsed; its pointers are valid until it returns.  layout: AMPLI_RECORDS_U24, or
- * AMPLI_RECORDS_I32 for a chunk holding a count above 2^24 - 2.  prim [n][P] records, ext [n][E] records (E, dup_off,
+ * order, while the next ones are being parsed; its pointers are valid until it returns.  layout: the narrowest the chunk's
+ * counts fit -- AMPLI_RECORDS_U16 (every count <= 65534), AMPLI_RECORDS_U24 (<= 2^24 - 2) or AMPLI_RECORDS_I32; the
+ * environment variable AMPLISOLVE_RECORDS = u16 | u24 | i32 sets the narrowest the packer may choose.  prim [n][P] records, ext [n][E] records (E, dup_off,
  * ext_pos are the CHUNK's own); line_prim / line_ext with keep_line_no; irregular: n_irregular x {sample in chunk, record
  * slot, occurrence, RD column} for lines with RD != A+C+G+T.  A negative strand count (reverse above total) or a count
  * beyond int32 ends the stream with AMPLI_E_RANGE.  Return non-zero from the callback to stop. */

@@ -65,7 +65,7 @@ def test_chunks_hold_the_records_of_the_dense_array(panel, aseq, chunk_bytes, th
     assert sum(c["n"] for c in chunks) == co.S and [c["first"] for c in chunks] == list(np.cumsum([0] + [c["n"] for c in chunks[:-1]]))
     if chunk_bytes == 1 and threads:
         assert len(chunks) > 1  # really streamed in pieces
-    assert all(c["layout"] == 2 for c in chunks)  # 24-byte records: what the command lines upload
+    assert all(c["layout"] == 1 for c in chunks)  # 16-byte records (every count <= 65534): what the command lines upload for such a cohort
     got, got_lines = dense_from_chunks(chunks, co.P, co.S)
     exp, exp_lines = dense_from_cohort(co)
     for s in range(co.S):
@@ -105,16 +105,30 @@ def test_reverse_count_above_total_is_a_range_error(tmp_path):
     assert "(-6)" in str(e.value) and "negative" in str(e.value)  # AMPLI_E_RANGE
 
 
-def test_a_count_beyond_24_bits_widens_only_its_chunk(tmp_path):
+def test_a_count_beyond_the_layout_widens_its_chunk_and_at_most_the_next(tmp_path, monkeypatch):
+    """The packer takes the narrowest layout a chunk's counts fit: uint16, 24 bits, int32.  A chunk is packed first in the
+    layout the one before it needed, and again, wider, if a count does not fit; the chunk after an outlier is the only
+    other one that may come out wider than it needs."""
     big = (1 << 24) + 5
-    files = {f"S{i}": [_line(100 + j, 900 + i, 3, 2, 1, (450, 1, 1, 0)) for j in range(5)] for i in range(4)}
-    files["S2"][3] = _line(103, big * 2, 3, 2, 1, (big, 1, 1, 0))
+    files = {f"S{i}": [_line(100 + j, 900 + i, 3, 2, 1, (450, 1, 1, 0)) for j in range(5)] for i in range(6)}
+    files["S2"][3] = _line(103, big * 2, 3, 2, 1, (big, 1, 1, 0))       # beyond 24 bits
+    files["S4"][1] = _line(101, 70_000 * 2, 3, 2, 1, (70_000, 1, 1, 0))  # beyond uint16, inside 24 bits
     bed, ref, nd = _write_panel(tmp_path, files)
     co = HostCohort(bed, nd, refbases_file=ref)
     chunks = co.stream_chunks(nd, chunk_bytes=1, threads=1)
-    assert len(chunks) == 4
-    layouts = {co.names[c["first"]]: c["layout"] for c in chunks}
-    assert layouts["S2"] == 0 and all(v == 2 for k, v in layouts.items() if k != "S2")
+    assert len(chunks) == 6
+    order = [co.names[c["first"]] for c in chunks]
+    layouts = [c["layout"] for c in chunks]
+    need = {"S2": 0, "S4": 2}
+    for i, (name, lay) in enumerate(zip(order, layouts)):
+        want = need.get(name, 1)
+        prev = need.get(order[i - 1], 1) if i else 1
+        wide = {1: 0, 2: 1, 0: 2}
+        assert lay == want or (wide[lay] > wide[want] and lay == prev), (order, layouts)
+    assert layouts[order.index("S2")] == 0 and layouts[order.index("S4")] in (2, 0)
+    monkeypatch.setenv("AMPLISOLVE_RECORDS", "u24")  # the narrowest the packer may choose
+    assert all(c["layout"] in (2, 0) for c in co.stream_chunks(nd, chunk_bytes=1, threads=1))
+    monkeypatch.delenv("AMPLISOLVE_RECORDS")
     got, _ = dense_from_chunks(chunks, co.P, co.S)
     exp, _ = dense_from_cohort(co)
     for s in range(co.S):
