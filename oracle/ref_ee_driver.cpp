@@ -10,6 +10,10 @@
 // would have produced are passed in as files in the formats storeReference
 // (EE:963) and storeDuplicates (EE:1012) read.
 //
+// usage: ee_ref_driver --default <bed> <refbases.txt> <dups.txt> <default_error> <out_dir>
+//   the germline_dir=not_available branch of main() (EE:472-506): storeReference, storeDuplicates, then the reference's
+//   generateFinalOutput_default (EE:2948-3043) writes <out_dir>/positionSpecificNoise_default.txt.  default_error is
+//   passed as main() would after its own conversion (EE:353-363: atof, and 0.01 for a value <= 0).
 // usage: ee_ref_driver <bed> <refbases.txt> <dups.txt> <germline_dir> <C> <cov> <out_dir> [dump_prefix]
 //   writes <out_dir>/positionSpecificNoise_<C>.txt exactly as the reference does; with dump_prefix also
 //   <dump_prefix>.order (sample visit order), <dump_prefix>.counts (Count_Hash: the integer quorum
@@ -44,6 +48,9 @@ void generateFinalOutput(float C_value_float, char *panelDesign,
                          std::unordered_map<std::string, std::string> &CountHash,
                          std::unordered_map<std::string, std::string> &RatioHash);
 
+void generateFinalOutput_default(float C_value_float, char *panelDesign, std::unordered_map<std::string, std::string> &Reference_Hash,
+                                 std::unordered_map<std::string, std::string> &Duplicate_Hash, char *output_dir, float defaultError);
+
 extern std::unordered_map<std::string, std::string> GermlineCountFileList_Hash;
 extern std::unordered_map<std::string, std::string> ReferenceBase_Hash;
 extern std::unordered_map<std::string, std::string> DuplicatePosition_Hash;
@@ -60,6 +67,13 @@ static double now_s()
 
 int main(int argc, char **argv)
 {
+    if (argc == 7 && strcmp(argv[1], "--default") == 0) {
+        storeReference(argv[3], ReferenceBase_Hash);      // EE:493
+        storeDuplicates(argv[4], DuplicatePosition_Hash); // EE:500
+        generateFinalOutput_default(0.0f, argv[2], ReferenceBase_Hash, DuplicatePosition_Hash, argv[6], (float)std::atof(argv[5])); // EE:501 (C is unused there)
+        std::cout.flush();
+        return 0;
+    }
     if (argc < 8) {
         fprintf(stderr, "usage: %s <bed> <refbases> <dups> <germline_dir> <C> <cov> <out_dir> [dump_prefix]\n", argv[0]);
         return 2;

@@ -158,3 +158,22 @@ def test_irregular_lines_oracle_reproduces_the_reference_table():
         # and without the column the table is NOT the reference's: the fixture really exercises it
         acc0 = orc.error_reduce(co.recs, co.P, C_value, cov, E=co.E, dup_off=co.dup_off)
         assert not np.array_equal(acc0["gm_n"], acc["gm_n"])
+
+
+@pytest.mark.parametrize("panel,arg,tag", [("mini_edge", "0.012", "0.0120"), ("mini_edge", "0.01", "0.0100"), ("mini_edge", "0", "0.0100"),
+                                           ("mini_edge", "-3", "0.0100"), ("mini_edge", "junk", "0.0100"), ("mini_edge", "0.00049", "0.00049"),
+                                           ("mini_edge", "0.123456", "0.123456"), ("mini_edge", "7", "7"), ("toy_subset", "0.012", "0.0120")])
+def test_default_table_mode_is_byte_identical_to_the_reference(tmp_path, panel, arg, tag):
+    """germline_dir=not_available (EE:472-506): the table generateFinalOutput_default (EE:2948-3043) itself wrote for the same
+    panel (tests/golden/make_golden_default.py, the reference compiled where it lies) -- through the drop-in command line, which
+    needs no GPU for this mode.  default_error <= 0 or unparsable becomes 0.01 in main() (EE:353-363: atof)."""
+    import subprocess
+
+    d = f"{G}/{panel}"
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "amplisolve_amd", "bin", "AmpliSolveErrorEstimation")
+    out = tmp_path / "o"
+    r = subprocess.run([exe, f"panel_design={d}/panel.bed", "reference_genome=unused.fa", "germline_dir=not_available", "C_value=0.002", "coverage_cutoff=100",
+                        f"default_error={arg}", f"output_dir={out}"], capture_output=True, text=True,
+                       env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1", AMPLISOLVE_REFBASES_FILE=f"{d}/refbases.txt"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (out / "positionSpecificNoise_default.txt").read_bytes() == open(f"{d}/expected_positionSpecificNoise_default_{tag}.txt", "rb").read()
