@@ -19,6 +19,10 @@ class AmpliError(RuntimeError):
     pass
 
 
+class AmpliNoDevice(AmpliError):
+    """hipGetDeviceCount found nothing (or failed): the message carries HIP's own error name and text"""
+
+
 class AccTable(C.Structure):
     """mirror of ampli_acc_table (include/amplisolve_hip.h)"""
     _fields_ = [("P", i64), ("snt", vp), ("srd", vp), ("cnt", vp), ("nrec", vp), ("gm_n", vp),
@@ -43,6 +47,7 @@ HIP_SYMBOLS = {
     "ampli_abi_version": (C.c_int, []),
     "ampli_strerror": (C.c_char_p, [C.c_int]),
     "ampli_device_count": (C.c_int, []),
+    "ampli_device_probe": (C.c_int, [C.c_char_p, C.c_size_t]),
     "ampli_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
     "ampli_ctx_destroy": (None, [vp]),
     "ampli_last_error": (C.c_char_p, [vp]),

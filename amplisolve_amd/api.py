@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from dataclasses import dataclass
 
-from ._lib import AccTable, AmpliError, Call, Records, hip_lib
+from ._lib import AccTable, AmpliError, AmpliNoDevice, Call, Records, hip_lib
 
 NT = "ACGT"
 POISSON_FULL = 0
@@ -85,8 +85,15 @@ class Context:
         import torch
 
         self.lib = hip_lib()
-        if self.lib.ampli_device_count() <= 0 or not torch.cuda.is_available():
-            raise AmpliError("no MI355X visible: libamplisolve_hip.so has no CPU fallback")
+        # two different probes, two different messages (a failure here once could not be told apart afterwards)
+        msg = C.create_string_buffer(256)
+        n = self.lib.ampli_device_probe(msg, len(msg))
+        if n <= 0:
+            why = msg.value.decode() if n < 0 else "hipGetDeviceCount succeeded and counted 0 devices"
+            raise AmpliNoDevice(f"no MI355X visible to libamplisolve_hip.so ({why}); there is no CPU fallback")
+        if not torch.cuda.is_available():
+            raise AmpliError(f"libamplisolve_hip.so sees {n} device(s) but torch.cuda.is_available() is False "
+                             f"(torch {torch.__version__}, hip {getattr(torch.version, 'hip', None)}): the tensors this API hands out need torch's runtime")
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         stream = C.c_void_p(-1) if own_stream else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

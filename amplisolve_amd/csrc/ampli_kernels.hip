@@ -52,6 +52,19 @@ extern "C" int ampli_device_count(void)
     return n;
 }
 
+// the same, saying WHY when there is nothing to count: the number of devices, or -1 with hipGetDeviceCount's own error
+// name and text in msg ("hipErrorNoDevice: no ROCm-capable device is detected")
+extern "C" int ampli_device_probe(char *msg, size_t cap)
+{
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (msg && cap) msg[0] = 0;
+    if (e == hipSuccess) return n;
+    (void)hipGetLastError(); // do not leave the error behind for the next call's check
+    if (msg && cap) snprintf(msg, cap, "%s: %s", hipGetErrorName(e), hipGetErrorString(e));
+    return -1;
+}
+
 extern "C" int ampli_ctx_create(int device_ordinal, void *stream, ampli_ctx **out)
 {
     if (!out) return AMPLI_E_INVALID;

@@ -191,12 +191,21 @@ bool parse_header(const unsigned char *buf, size_t n, Header &h, const std::stri
     return true;
 }
 
-// list the complete, well-formed alignment records of buf[from, n); returns the offset of the first incomplete one
-size_t scan_records(const unsigned char *buf, size_t from, size_t n, std::vector<uint64_t> &off, int64_t &malformed)
+// A block_size beyond this is not a record but a corrupt or desynchronised stream (the longest reads there are -- megabases
+// of nanopore sequence -- stay two orders of magnitude below).  Treating it as "incomplete, wait for more bytes" would carry
+// the rest of the file from batch to batch and end in a silently truncated pileup.
+constexpr size_t BAM_MAX_RECORD = (size_t)1 << 28;
+
+// list the complete, well-formed alignment records of buf[from, n); returns the offset of the first incomplete one.
+// stream_off: offset of buf[0] in the uncompressed stream (for messages).
+size_t scan_records(const unsigned char *buf, size_t from, size_t n, std::vector<uint64_t> &off, int64_t &malformed, const std::string &path,
+                    uint64_t stream_off)
 {
     size_t o = from;
     while (n - o >= 4) {
         const size_t bs = le32(buf + o);
+        if (bs > BAM_MAX_RECORD)
+            throw Error{AMPLI_E_INVALID, path + ": corrupt BAM record at uncompressed byte " + std::to_string(stream_off + o) + " (block_size " + std::to_string(bs) + ")"};
         if (n - o - 4 < bs) break; // incomplete: carried over to the next batch
         bool ok = bs >= 32;
         if (ok) {
@@ -252,11 +261,13 @@ void bam_scan(const std::string &bam, int n_threads, int64_t stats[4])
     if (!parse_header(buf.data(), buf.size(), h, bam)) throw Error{AMPLI_E_INVALID, bam + ": truncated BAM header"};
     std::vector<uint64_t> off;
     int64_t malformed = 0;
-    const size_t end = scan_records(buf.data(), h.end, buf.size(), off, malformed);
+    const size_t end = scan_records(buf.data(), h.end, buf.size(), off, malformed, bam, 0);
+    if (end != buf.size())
+        throw Error{AMPLI_E_INVALID, bam + ": " + std::to_string(buf.size() - end) + " bytes behind the last complete alignment record (truncated or corrupt file)"};
     stats[0] = (int64_t)off.size();
     stats[1] = (int64_t)total;
     stats[2] = (int64_t)h.ref_names.size();
-    stats[3] = malformed + (end != buf.size() ? 1 : 0);
+    stats[3] = malformed;
 }
 
 int run_compute_counts(const CcArgs &a)
@@ -333,6 +344,7 @@ int run_compute_counts(const CcArgs &a)
         int64_t P = 0, n_records = 0, malformed = 0;
 
         std::vector<unsigned char> carry; // the incomplete record (or header) at the end of the previous batch
+        uint64_t stream_pos = 0;          // uncompressed bytes inflated so far (for messages)
         size_t b0 = 0;
         int slot = 0;
         while (b0 < blocks.size()) {
@@ -355,6 +367,7 @@ int run_compute_counts(const CcArgs &a)
             if (!have_header) {
                 if (!parse_header(hb.p, n, hdr, a.bam)) { // header longer than this batch: keep everything and read on
                     carry.assign(hb.p, hb.p + n);
+                    stream_pos += bytes;
                     b0 = b1;
                     if (b0 >= blocks.size()) throw Error{AMPLI_E_INVALID, a.bam + ": truncated BAM header"};
                     continue;
@@ -387,7 +400,8 @@ int run_compute_counts(const CcArgs &a)
                 }
             }
             offs[slot].clear();
-            const size_t done = scan_records(hb.p, from, n, offs[slot], malformed);
+            const size_t done = scan_records(hb.p, from, n, offs[slot], malformed, a.bam, stream_pos - carry.size());
+            stream_pos += bytes;
             carry.assign(hb.p + done, hb.p + n);
             n_records += (int64_t)offs[slot].size();
             if (P > 0 && !offs[slot].empty()) {
@@ -407,7 +421,8 @@ int run_compute_counts(const CcArgs &a)
             slot ^= 1;
         }
         if (!have_header) throw Error{AMPLI_E_INVALID, a.bam + ": truncated BAM header"};
-        if (!carry.empty()) ++malformed; // bytes behind the last complete record
+        if (!carry.empty()) // a cut-off file or a desynchronised stream: no counts file is written from part of the reads
+            throw Error{AMPLI_E_INVALID, a.bam + ": " + std::to_string(carry.size()) + " bytes behind the last complete alignment record (truncated or corrupt file)"};
 
         std::vector<int32_t> counts((size_t)P * 8, 0);
         uint64_t st[2] = {0, 0};

@@ -72,6 +72,9 @@ int ampli_abi_version(void);
 const char *ampli_strerror(int code);
 /* number of HIP devices visible; 0 when there is none (never initialises a device) */
 int ampli_device_count(void);
+/* the same with the reason when the answer is not a count: the number of devices, or -1 with hipGetDeviceCount's error
+ * name and text in msg (cap bytes) */
+int ampli_device_probe(char *msg, size_t cap);
 
 /* stream: the hipStream_t to enqueue on (e.g. torch's current stream); NULL is the
  * device's default (null) stream; AMPLI_STREAM_OWN lets the context create and own a

@@ -27,6 +27,20 @@ def _native_built():
     yield
 
 
+def _gpu_holders():
+    """who is on the GPU right now (for the log of a failed initialisation): rocm-smi's process list and the KFD's own"""
+    import subprocess
+
+    out = []
+    for cmd in (["rocm-smi", "--showpids"], ["sh", "-c", "ls /sys/class/kfd/kfd/proc 2>/dev/null | tr '\\n' ' '"]):
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=20)
+            out.append(f"$ {' '.join(cmd)}\n{(r.stdout + r.stderr).strip()[-1500:]}")
+        except Exception as e:  # noqa: BLE001
+            out.append(f"$ {' '.join(cmd)}: {e!r}")
+    return "\n".join(out)
+
+
 @pytest.fixture(scope="session")
 def ctx():
     import torch
@@ -34,18 +48,22 @@ def ctx():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
+    import warnings
 
-    from amplisolve_amd import AmpliError, Context
+    from amplisolve_amd import AmpliNoDevice, Context
 
-    c = None
-    for attempt in range(3):  # seen once on a GPU box: the first in-process initialisation right after a burst of short-lived GPU
-        try:                  # processes found no device, while a process started a moment later did
-            c = Context(0)
-            break
-        except AmpliError:
-            if attempt == 2:
-                raise
-            time.sleep(2.0)
+    # Round 2 saw ONE first in-process initialisation fail right behind a burst of short-lived GPU processes (the command-line
+    # tests), with a message that could not say which probe had failed.  Now the error carries hipGetDeviceCount's own name and
+    # text, and this fixture does not swallow anything: it retries exactly that one error once, and only after it has put the
+    # error and the processes holding the GPU into the test log and a warning.  Every other failure is raised as it is.
+    try:
+        c = Context(0)
+    except AmpliNoDevice as e:
+        report = f"first Context(0) of the session failed: {e}\n{_gpu_holders()}"
+        print(report, file=sys.stderr, flush=True)
+        warnings.warn(report)
+        time.sleep(2.0)
+        c = Context(0)
     yield c
     c.close()
 

@@ -78,9 +78,10 @@ def borderline_triples(want=12, seed=5, gate=5.0, eps=1e-6, errs=(0.000001, 0.00
 
 
 # ---- BAM files for the pileup step (computeCounts): a minimal writer, BGZF framing included ----
-def write_bam(path, refs, reads, rng=None, max_block=60000, level=6):
+def write_bam(path, refs, reads, rng=None, max_block=60000, level=6, corrupt_block_size=None):
     """refs: [(name, length)]; reads: dicts with ref_id, pos (0-based), mapq, flag, cigar [(op char, len)], seq (str), qual (list),
-    optional name.  The stream is cut into BGZF blocks of random sizes (records span block boundaries)."""
+    optional name.  The stream is cut into BGZF blocks of random sizes (records span block boundaries).
+    corrupt_block_size = (k, value): record k is written with that block_size instead of its length (a corrupt file)."""
     import struct
     import zlib
 
@@ -99,7 +100,7 @@ def write_bam(path, refs, reads, rng=None, max_block=60000, level=6):
         cig = b"".join(struct.pack("<I", (n << 4) | ops.index(op)) for op, n in r["cigar"])
         body = struct.pack("<iiBBHHHiiii", r["ref_id"], r["pos"], len(name), r["mapq"], 4680, len(r["cigar"]), r["flag"], len(seq), -1, -1, 0)
         body += name + cig + bytes(packed) + bytes(r["qual"])
-        raw += struct.pack("<i", len(body)) + body
+        raw += struct.pack("<I", corrupt_block_size[1] if corrupt_block_size and corrupt_block_size[0] == k else len(body)) + body
     out = bytearray()
     o = 0
     while o < len(raw):

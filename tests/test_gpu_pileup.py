@@ -130,3 +130,16 @@ def test_long_reads_take_the_unstaged_walk(tmp_path):
     assert sum(len(x["seq"]) for x in recs[:256]) > 56 * 1024
     want = po.aseq_text(lines, po.pileup(refs, recs, [(c, p) for c, p, *_ in lines], 20, 20), 1)
     assert (tmp_path / "L.PILEUP.ASEQ").read_text() == want
+
+
+def test_corrupt_bam_ends_in_an_error_and_no_counts_file(tmp_path):
+    """A block_size gone wrong in the middle of the file: computeCounts names the place, exits non-zero under
+    AMPLISOLVE_STRICT_EXIT and writes no .PILEUP.ASEQ (round 2 wrote one from the reads before the damage and exited 0)."""
+    rng = np.random.default_rng(21)
+    reads = helpers.random_amplicon_reads(rng, REFS, AMPS, 800)
+    helpers.write_bam(tmp_path / "C.bam", REFS, reads, rng=rng, max_block=5000, corrupt_block_size=(400, 0x7FFFFFFF))
+    _write_vcf(tmp_path / "v.txt", _positions(rng))
+    r = subprocess.run([f"{BIN}/computeCounts", f"vcf={tmp_path}/v.txt", f"bam={tmp_path}/C.bam", "mbq=20", "mrq=20", "mdc=0", f"out={tmp_path}"],
+                       capture_output=True, text=True, timeout=300, env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1"))
+    assert r.returncode != 0 and "corrupt BAM record at uncompressed byte" in r.stdout
+    assert not os.path.exists(tmp_path / "C.PILEUP.ASEQ")

@@ -82,6 +82,17 @@ def test_host_drops_malformed_records_and_rejects_broken_files(tmp_path):
     raw = open(tmp_path / "m.bam", "rb").read()
     (tmp_path / "t.bam").write_bytes(raw[: len(raw) // 2])
     assert host_lib().ampli_host_bam_scan(str(tmp_path / "t.bam").encode(), 1, st) != 0
+    # a block_size gone wrong in the middle of the file is a corrupt stream, not "a record that continues in the next batch"
+    # (that reading carried the rest of the file along and ended in a silently truncated pileup): the reader says where and fails
+    rng = np.random.default_rng(3)
+    reads = helpers.random_amplicon_reads(rng, REFS, [(0, 1000, 1120)], 400)
+    helpers.write_bam(tmp_path / "c.bam", REFS, reads, rng=rng, max_block=3000, corrupt_block_size=(200, 0x7FFFFFFF))
+    assert host_lib().ampli_host_bam_scan(str(tmp_path / "c.bam").encode(), 2, st) != 0
+    assert b"corrupt BAM record at uncompressed byte" in host_lib().ampli_host_last_error()
+    # ... and one that is merely too short leaves the stream out of step: whatever follows, the file does not end on a record boundary
+    helpers.write_bam(tmp_path / "d.bam", REFS, reads[:50], rng=rng, max_block=3000, corrupt_block_size=(49, 31))
+    rc = host_lib().ampli_host_bam_scan(str(tmp_path / "d.bam").encode(), 2, st)
+    assert rc != 0 or st[3] >= 1
     (tmp_path / "n.bam").write_bytes(b"this is not a BAM file, not even gzip" * 3)
     assert host_lib().ampli_host_bam_scan(str(tmp_path / "n.bam").encode(), 1, st) != 0
     assert b"BGZF" in host_lib().ampli_host_last_error()
