@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): rocprofv3 kernel-trace stats + PMC passes of the default bench command (kernels only:
-# the CPU baseline and end-to-end legs are switched off).  Outputs under gpurun_out/prof_r02/ (merged back by gpurun);
-# tools/make_profile_summary.py turns them into the files committed under profiles/r02/.
+# the CPU baseline and end-to-end legs are switched off).  Outputs under gpurun_out/prof_<round>/ (ROUND, default r03) (merged back by gpurun);
+# tools/make_profile_summary.py turns them into the files committed under profiles/<round>/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof_r02
+OUT=$R/gpurun_out/prof_${ROUND:-r03}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0"

@@ -2,8 +2,8 @@
 """Turn gpurun_out/prof_final/ (tools/collect_profiles.sh) into the committed summaries under profiles/<round>/."""
 import collections, csv, glob, json, os, shutil, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof_r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
 def newest(pattern):
