@@ -17,15 +17,16 @@ ctx = Context(0)
 normals = ctx.synth_fill(P, S, seed=SEED, depth=2000)
 tumours = ctx.synth_fill(P, T, seed=SEED, depth=2000, tumour=True)
 ref_code = ctx.synth_ref(P, seed=SEED)
-n24, _ = ctx.pack24(normals)
-t24, _ = ctx.pack24(tumours)
+LAYOUT = os.environ.get("SWEEP_LAYOUT", "u24")  # u24 | u16 | i32
+n24, _ = (normals, True) if LAYOUT == "i32" else ctx.pack(normals, LAYOUT)
+t24, _ = (tumours, True) if LAYOUT == "i32" else ctx.pack(tumours, LAYOUT)
 del normals, tumours
-ctx.set_record_layout("u24")
+ctx.set_record_layout(LAYOUT)
 fin = ctx.error_estimate(n24, P, 0.002, 100)
 res = ctx.poisson_call(t24, P, fin.thr, ref_code, 100, capacity=1 << 20)
 base_mask = res["call_mask"].clone()
 n_base = ctx.n_calls_total(res)
-BYTES = 24 * P * T + 33 * P + P * T
+BYTES = {'u24': 24, 'u16': 16, 'i32': 32}[LAYOUT] * P * T + 33 * P + P * T
 
 
 def call():
