@@ -5,8 +5,11 @@ One "step" = one pass of the hot path over one synthetic batch that is already
 resident in HBM: error_reduce over the rank's normal-sample shard -> (N>1: RCCL
 merge of the accumulator table) -> error_finalize -> poisson_call over the
 rank's tumour shard.  Workload at N=1: BASELINE.json configs[2], the one the
-metric's target is quoted on (100k positions x 256 normals x 96 tumours);
-weak scaling: every rank owns a shard of that size.
+metric's target is quoted on (100k positions x 256 normals x 96 tumours).
+N>1: strong scaling of configs[3] (1024 normals + 1024 tumours split N ways);
+started without a launcher, `--gpus N` starts its own N ranks (torch.distributed.run)
+before it touches the GPU, and every N>1 line carries the same job's one-GPU time
+(strong_base), the efficiency against it and a communication block.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt).  `value` counts
 position-evaluations: one (position, sample) record pushed through its half of

@@ -17,6 +17,11 @@ V = {
     "lb256": [("template <int LAY>\n__global__ __launch_bounds__(256, 8) void poisson_stream_kernel(", "template <int LAY>\n__global__ __launch_bounds__(256) void poisson_stream_kernel(")],
     # poisson_stream without clearing the call mask (what do the mask stores cost?)
     "nomask": [("        for (size_t o = w0 + lane; o < w1; o += 64) ((unsigned *)call_mask)[o] = 0u;", "        (void)w1; // variant: mask not cleared")],
+    # error_reduce with an XCD-contiguous tile mapping: workgroup b runs on XCD b % 8; give XCD k the k-th contiguous eighth of the
+    # tiles (adjacent tiles -> same L2 / same translation) instead of every eighth tile
+    "red_xcd": [("    const long long p_raw = (long long)blockIdx.x * W + (lane % W);",
+                 "    const unsigned tiles8_ = (gridDim.x + 7u) / 8u;\n    const long long tile_ = (long long)(blockIdx.x & 7u) * tiles8_ + (blockIdx.x >> 3);\n    if (tile_ * W >= P) return;\n    const long long p_raw = tile_ * W + (lane % W);"),
+                ("    dim3 grid((unsigned)tiles, (unsigned)splits);", "    dim3 grid((unsigned)((tiles + 7) / 8 * 8), (unsigned)splits);")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }
