@@ -22,6 +22,14 @@ V = {
     "red_xcd": [("    const long long p_raw = (long long)blockIdx.x * W + (lane % W);",
                  "    const unsigned tiles8_ = (gridDim.x + 7u) / 8u;\n    const long long tile_ = (long long)(blockIdx.x & 7u) * tiles8_ + (blockIdx.x >> 3);\n    if (tile_ * W >= P) return;\n    const long long p_raw = tile_ * W + (lane % W);"),
                 ("    dim3 grid((unsigned)tiles, (unsigned)splits);", "    dim3 grid((unsigned)((tiles + 7) / 8 * 8), (unsigned)splits);")],
+    # TIMING ONLY (wrong results): error_reduce reading a TILE-MAJOR arrangement -- a wave's consecutive sample rows are contiguous
+    # (64 records apart) and tiles lie S*64 + PAD records apart -- out of the same buffer.  PAD = 0 / 64 / 192 records.
+    "red_tilemajor0": [("    const size_t row_step = (size_t)rv.row_stride * RB; // bytes between the same position of consecutive samples\n    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;",
+                        "    const size_t row_step = (size_t)64 * RB;\n    const char *__restrict__ q = rv.base + ((size_t)blockIdx.x * ((size_t)S * 64 + 0) + (size_t)min(s0, S - 1) * 64 + (size_t)(lane % W)) * RB;")],
+    "red_tilemajor64": [("    const size_t row_step = (size_t)rv.row_stride * RB; // bytes between the same position of consecutive samples\n    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;",
+                         "    const size_t row_step = (size_t)64 * RB;\n    const char *__restrict__ q = rv.base + ((size_t)blockIdx.x * ((size_t)S * 64 + 64) + (size_t)min(s0, S - 1) * 64 + (size_t)(lane % W)) * RB;")],
+    "red_tilemajor192": [("    const size_t row_step = (size_t)rv.row_stride * RB; // bytes between the same position of consecutive samples\n    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;",
+                          "    const size_t row_step = (size_t)64 * RB;\n    const char *__restrict__ q = rv.base + ((size_t)blockIdx.x * ((size_t)S * 64 + 192) + (size_t)min(s0, S - 1) * 64 + (size_t)(lane % W)) * RB;")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }
