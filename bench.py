@@ -364,6 +364,12 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # no GPU call has been made in this process
+    # ONE JSON line on stdout and nothing else: RCCL prints a version banner to stdout when its first communicator comes up,
+    # and a line in front of the result is a line a parser may take for it.  File descriptor 1 points at stderr from here on
+    # (C libraries included); the result goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.config is None:
         args.config = "c4" if max(world, args.gpus) > 1 else "c3"
@@ -975,7 +981,8 @@ def main():
                 out["e2e"] = {"c2": e2e_leg("c2", CONFIGS["c2"]), args.config: e2e_leg(args.config, cfg, ref_files=6)}
             except Exception as e:
                 out["e2e"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
