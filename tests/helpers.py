@@ -156,3 +156,50 @@ def random_amplicon_reads(rng, refs, amplicons, n_reads, read_len=(60, 140)):
                           qual=[int(x) for x in rng.choice([2, 10, 19, 20, 21, 30, 40], size=qlen)]))
     reads.sort(key=lambda r: (r["ref_id"] if r["ref_id"] >= 0 else 1 << 30, r["pos"]))
     return reads
+
+
+def write_fresh_panel(d, seed, depth=None, S=11, amplicons=7):
+    """A freshly drawn panel in directory d (pathlib): p.bed (every second amplicon overlaps its predecessor by 25 positions ->
+    positions listed twice), r.txt (reference bases), d.txt (duplicated positions), N/S??.PILEUP.ASEQ (absent lines, heterozygous
+    sites, low-coverage cells from the synthetic generator).  Returns the number of duplicated positions."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    chroms = ["chr1", "chr2", "chr7", "chrX"]
+    rows, walk = [], []
+    for i in range(amplicons):
+        c = chroms[i % len(chroms)]
+        start = 100_000 + (i // len(chroms)) * 50_000
+        if i % 2 == 1:
+            c, start = rows[-1][0], rows[-1][2] - 24
+        n = int(rng.integers(150, 260))
+        rows.append((c, start, start + n - 1))
+        walk += [(c, start + j) for j in range(n)]
+    W = len(walk)
+    recs = synth_recs(W, S, seed=seed, depth=int(rng.choice([400, 2000, 6000])) if depth is None else depth)
+    uniq = {}
+    for k in walk:
+        uniq.setdefault(k, len(uniq))
+    refb = synth_ref(len(uniq), seed=seed)
+    (d / "N").mkdir()
+    with open(d / "p.bed", "w") as f:
+        f.write("".join(f"{c}\t{a}\t{b}\tAMPL{i}\trs{i}\tGENE{i}\n" for i, (c, a, b) in enumerate(rows)))
+    seen, dups = set(), []
+    with open(d / "r.txt", "w") as f:
+        for k in walk:
+            f.write(f"{k[0]}\t{k[1]}\t{'ACGT'[refb[uniq[k]]]}\n")
+            if k in seen and k not in dups:
+                dups.append(k)
+            seen.add(k)
+    with open(d / "d.txt", "w") as f:
+        f.write("".join(f"{c}\t{p}\n" for c, p in sorted(dups)))
+    for s_ in range(S):
+        r = recs[s_].astype(np.int64)
+        with open(d / "N" / f"S{s_:02d}.PILEUP.ASEQ", "w") as f:
+            f.write("chr\tpos\tdbsnp\tMAF\tref\talt\tA\tC\tG\tT\tRD\tArs\tCrs\tGrs\tTrs\n")
+            for w, (c, p) in enumerate(walk):
+                if r[w, 0] == np.iinfo(np.int32).min:
+                    continue  # the sample has no line for this amplicon position
+                tot = r[w, :4] + r[w, 4:]
+                f.write(f"{c}\t{p}\t.\t.\t.\t.\t{tot[0]}\t{tot[1]}\t{tot[2]}\t{tot[3]}\t{tot.sum()}\t{r[w,4]}\t{r[w,5]}\t{r[w,6]}\t{r[w,7]}\n")
+    return len(dups)
