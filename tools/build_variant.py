@@ -30,6 +30,10 @@ V = {
                          "    const size_t row_step = (size_t)64 * RB;\n    const char *__restrict__ q = rv.base + ((size_t)blockIdx.x * ((size_t)S * 64 + 64) + (size_t)min(s0, S - 1) * 64 + (size_t)(lane % W)) * RB;")],
     "red_tilemajor192": [("    const size_t row_step = (size_t)rv.row_stride * RB; // bytes between the same position of consecutive samples\n    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;",
                           "    const size_t row_step = (size_t)64 * RB;\n    const char *__restrict__ q = rv.base + ((size_t)blockIdx.x * ((size_t)S * 64 + 192) + (size_t)min(s0, S - 1) * 64 + (size_t)(lane % W)) * RB;")],
+    # poisson_stream with the prefilter test written branch-free (bitwise & instead of &&: hipcc wraps every short-circuit in an
+    # exec-mask block -- s_and_saveexec / s_or exec / s_cbranch_execz around three vector instructions)
+    "ps_branchfree": [("            const bool skip_fw = exact && (unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)fw[nt] <= c_fw * te[0][nt];\n            const bool skip_bw = exact && (unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)bw[nt] <= c_bw * te[1][nt];\n            if (live && nt != ref && !skip_fw && !skip_bw) pushmask |= 1u << nt;",
+                       "            const int skip_fw = (int)exact & (int)((unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT) & (int)((float)fw[nt] <= c_fw * te[0][nt]);\n            const int skip_bw = (int)exact & (int)((unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT) & (int)((float)bw[nt] <= c_bw * te[1][nt]);\n            pushmask |= (unsigned)((int)live & (int)(nt != ref) & (skip_fw ^ 1) & (skip_bw ^ 1)) << nt;")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }
