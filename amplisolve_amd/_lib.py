@@ -164,6 +164,9 @@ HOST_SYMBOLS = {
     "ampli_host_stream_chunks": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int, i64, CHUNK_FN, vp]),
     "ampli_host_write_error_table": (C.c_int, [vp, vp, vp, vp, vp, C.c_char_p]),
     "ampli_host_read_error_table": (C.c_int, [C.c_char_p, C.POINTER(vp), vp, i64]),
+    "ampli_host_read_error_table_vcf": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(vp), vp, i64]),
+    "ampli_host_table_cell": (C.c_char_p, [vp, i64, i32]),
+    "ampli_host_context": (C.c_int, [vp, i64, C.c_char, C.c_char_p, C.c_char_p, i32]),
     "ampli_host_run_error_estimation": (C.c_int, [C.c_char_p] * 8),
     "ampli_host_run_variant_calling": (C.c_int, [C.c_char_p] * 5),
     "ampli_host_run_error_estimation_sharded": (C.c_int, [C.c_char_p] * 8 + [C.POINTER(HostShard)]),

@@ -129,12 +129,12 @@ extern "C" int ampli_host_write_error_table(const ampli_host_cohort *h, const fl
     return 0;
 }
 
-extern "C" int ampli_host_read_error_table(const char *path, ampli_host_cohort **out, float *thr_out, int64_t thr_capacity)
+extern "C" int ampli_host_read_error_table_vcf(const char *path, const char *dummy_vcf, ampli_host_cohort **out, float *thr_out, int64_t thr_capacity)
 {
     auto *h = new ampli_host_cohort();
     try {
         std::vector<float> thr;
-        panel_from_error_table(path, "", h->panel, thr);
+        panel_from_error_table(path, dummy_vcf ? dummy_vcf : "", h->panel, thr);
         h->cohort.P = h->panel.P();
         if (thr_out) {
             if ((int64_t)thr.size() > thr_capacity) throw Error{AMPLI_E_INVALID, "thr buffer too small"};
@@ -147,6 +147,32 @@ extern "C" int ampli_host_read_error_table(const char *path, ampli_host_cohort *
     }
     *out = h;
     return 0;
+}
+
+extern "C" int ampli_host_read_error_table(const char *path, ampli_host_cohort **out, float *thr_out, int64_t thr_capacity)
+{
+    return ampli_host_read_error_table_vcf(path, nullptr, out, thr_out, thr_capacity);
+}
+
+extern "C" const char *ampli_host_table_cell(const ampli_host_cohort *h, int64_t p, int32_t which)
+{
+    if (!h || p < 0 || p >= h->panel.P() || which < 0 || which > 8) return nullptr;
+    const Panel &pn = h->panel;
+    if (which == 0) return (size_t)p < pn.ref_base.size() ? pn.ref_base[(size_t)p].c_str() : nullptr;
+    const std::vector<std::string> &col = which <= 4 ? pn.thr_text[which - 1] : pn.germ_text[which - 5];
+    return (size_t)p < col.size() ? col[(size_t)p].c_str() : nullptr;
+}
+
+extern "C" int ampli_host_context(const ampli_host_cohort *h, int64_t p, char sub, char *down, char *up, int32_t cap)
+{
+    if (!h || !down || !up || cap <= 0 || p < 0 || p >= h->panel.P()) return AMPLI_E_INVALID;
+    const Panel &pn = h->panel;
+    const std::string &chrom = pn.chroms[(size_t)pn.pos_chrom[(size_t)p]];
+    const std::string d = kmer_down(pn, chrom, pn.pos_coord[(size_t)p]), u = kmer_up(pn, chrom, pn.pos_coord[(size_t)p]);
+    if ((int64_t)d.size() >= cap || (int64_t)u.size() >= cap) return AMPLI_E_INVALID;
+    memcpy(down, d.c_str(), d.size() + 1);
+    memcpy(up, u.c_str(), u.size() + 1);
+    return homopolymer_test(d, u, sub);
 }
 
 extern "C" int ampli_host_run_error_estimation(const char *panel_design, const char *reference_genome, const char *germline_dir,

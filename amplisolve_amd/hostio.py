@@ -144,6 +144,56 @@ def read_error_table(path):
     return ref, thr
 
 
+class ErrorTable:
+    """A positionSpecificNoise table as AmpliSolveVariantCalling keeps it after storeInputFile (VC:430-576): per unique
+    position (first row wins) the reference / duplicate / threshold / germ-max cells, and the sequence context of a call."""
+
+    def __init__(self, path, dummy_vcf=None):
+        lib = host_lib()
+        h = C.c_void_p()
+        rc = lib.ampli_host_read_error_table_vcf(_b(path), _b(dummy_vcf) if dummy_vcf else None, C.byref(h), None, 0)
+        if rc != 0:
+            raise AmpliError(lib.ampli_host_last_error().decode())
+        self._lib, self.h = lib, h
+        self.P = lib.ampli_host_cohort_P(h)
+        self.thr = np.empty((2, 4, self.P), np.float32)
+        h2 = C.c_void_p()
+        rc = lib.ampli_host_read_error_table(_b(path), C.byref(h2), self.thr.ctypes.data_as(C.c_void_p), self.thr.size)
+        if rc != 0:
+            raise AmpliError(lib.ampli_host_last_error().decode())
+        lib.ampli_host_cohort_free(h2)
+        self.dup = np.frombuffer((C.c_char * max(self.P, 1)).from_address(lib.ampli_host_cohort_dup_flag(h)), dtype=np.uint8)[:self.P].copy()
+
+    def key(self, p):
+        buf = C.create_string_buffer(256)
+        coord = C.c_int32()
+        self._lib.ampli_host_position(self.h, p, buf, 256, C.byref(coord))
+        return buf.value.decode(), coord.value
+
+    def cell(self, p, which):
+        """which: 0 reference, 1..4 threshold A/C/G/T, 5..8 germ-max A/C/G/T"""
+        v = self._lib.ampli_host_table_cell(self.h, p, which)
+        return None if v is None else v.decode()
+
+    def context(self, p, sub):
+        d, u = C.create_string_buffer(1024), C.create_string_buffer(1024)
+        flag = self._lib.ampli_host_context(self.h, p, sub.encode(), d, u, 1024)
+        if flag < 0:
+            raise AmpliError("ampli_host_context")
+        return d.value.decode(), u.value.decode(), flag
+
+    def close(self):
+        if self.h:
+            self._lib.ampli_host_cohort_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def sample_order(aseq_dir):
     lib = host_lib()
     buf = C.create_string_buffer(1 << 20)

@@ -92,6 +92,20 @@ int ampli_host_stream_chunks(const ampli_host_cohort *panel, const char *aseq_di
 int ampli_host_write_error_table(const ampli_host_cohort *h, const float *rate /*[2][4][P]*/, const uint8_t *code /*[4][P]*/,
                                  const float *germ_val /*[4][P]*/, const uint8_t *germ_present /*[4][P]*/, const char *path);
 int ampli_host_read_error_table(const char *path, ampli_host_cohort **out, float *thr_out /*[2][4][P]*/, int64_t thr_capacity);
+/* the same reader, also writing the by-product file storeInputFile writes (VC:437-441, 571: `chrom \t position \t. ...` per
+ * data row, repeated rows included; dummy_vcf NULL or "" = none) */
+int ampli_host_read_error_table_vcf(const char *path, const char *dummy_vcf, ampli_host_cohort **out, float *thr_out, int64_t thr_capacity);
+/* a table read that way, cell by cell as the caller keeps it -- what storeInputFile puts into its four maps (VC:505-560;
+ * the FIRST row of a repeated position wins): which = 0 reference cell (ReferenceBase_Hash), 1..4 threshold cell of A/C/G/T
+ * (Thresholds_Hash_Analytic), 5..8 germ-max cell of A/C/G/T (Germline_Max_Hash).  NULL for a panel that did not come from a
+ * table or an index out of range; the pointer lives as long as the cohort. */
+const char *ampli_host_table_cell(const ampli_host_cohort *h, int64_t p, int32_t which);
+
+/* ---- sequence context of a call (post-call annotation, VC:3307-3718): the 10 reference bases before and after position p
+ * of the panel as find_kmer_down / find_kmer_up spell them (a position outside the panel is "-|", or a bare "-" at the
+ * offsets -6, -3, -1 and +10) and homopolymerTest's flag for the substituted base `sub`.  down / up: caller's buffers of
+ * cap bytes (a cell of a table can be up to 49 characters, so 10 of them need <= 512).  Returns the flag (0 / 1), < 0 on error. */
+int ampli_host_context(const ampli_host_cohort *h, int64_t p, char sub, char *down, char *up, int32_t cap);
 
 /* ---- the two command lines as functions (need libamplisolve_hip.so + a GPU) ---- */
 int ampli_host_run_error_estimation(const char *panel_design, const char *reference_genome, const char *germline_dir,

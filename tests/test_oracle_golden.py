@@ -69,8 +69,85 @@ def test_mini_edge_table_is_byte_identical(tmp_path, tag, C, cov):
         assert set(np.unique(fin["code"])) >= {0, 1}
 
 
+VC_TABLES = {  # name under tests/golden/vc_ref/ -> the table the reference's storeInputFile was run on (make_golden_vc.py)
+    "toy_subset_0.0020": "toy_subset/expected_positionSpecificNoise_0.0020.txt",
+    "toy_subset_0.0100_cov500": "toy_subset/expected_positionSpecificNoise_0.0100_cov500.txt",
+    "toy_subset_default_0.0120": "toy_subset/expected_positionSpecificNoise_default_0.0120.txt",
+    "mini_edge_0.0020_cov100": "mini_edge/expected_positionSpecificNoise_0.0020_cov100.txt",
+    "mini_edge_0.0005_cov1": "mini_edge/expected_positionSpecificNoise_0.0005_cov1.txt",
+    "mini_edge_0.0500_cov1000": "mini_edge/expected_positionSpecificNoise_0.0500_cov1000.txt",
+    "mini_edge_default_7": "mini_edge/expected_positionSpecificNoise_default_7.txt",
+    "irregular_0.0020_cov100": "irregular/expected_positionSpecificNoise_0.0020_cov100.txt",
+    "context_edge": "vc_ref/context_edge.txt",
+    "toy_full_0.0020": "toy/positionSpecificNoise_0.0020.txt.gz",
+}
+
+
+def _vc_digests():
+    out = {}
+    for l in open(f"{G}/vc_ref/digests.txt"):
+        name, _, sha, _, n = l.split()
+        out[name] = (sha, int(n))
+    return out
+
+
+def _vc_table(name, tmp_path):
+    src = f"{G}/{VC_TABLES[name]}"
+    if not src.endswith(".gz"):
+        return src
+    dst = tmp_path / f"{name}.txt"
+    dst.write_bytes(gzip.open(src).read())
+    return str(dst)
+
+
+def _strtof(text):
+    """glibc strtof -- what std::stof (VC:889-890) calls -- as the float's bit pattern"""
+    import ctypes as C
+
+    libc = C.CDLL(None)
+    libc.strtof.restype = C.c_float
+    libc.strtof.argtypes = [C.c_char_p, C.c_void_p]
+    return np.float32(libc.strtof(text.encode(), None)).view(np.int32)
+
+
+@pytest.mark.parametrize("name", list(VC_TABLES))
+def test_error_table_reader_against_the_reference_maps(tmp_path, name):
+    """a5, reference-pinned: our reader's view of a table == the four maps the reference's own storeInputFile (VC:430-576,
+    compiled from the reference, oracle/_ref/vc_ref_driver) fills from the same file -- reference cell, duplicate entry,
+    threshold cell and germ-max cell of every key, the first row of a repeated position winning -- and the by-product
+    dummy VCF byte for byte.  The thresholds handed to the kernels are strtof of exactly those cells (VC:887-890)."""
+    from amplisolve_amd.hostio import ErrorTable
+
+    table = _vc_table(name, tmp_path)
+    t = ErrorTable(table, dummy_vcf=str(tmp_path / "dummy.vcf"))
+    lines = {"R": [], "D": [], "T": [], "G": []}
+    for p in range(t.P):
+        c, x = t.key(p)
+        key = f"{c}_{x}"
+        lines["R"].append(f"{key} {t.cell(p, 0)}")
+        if t.dup[p]:
+            lines["D"].append(f"{key} {x}")
+        for nt in range(4):
+            lines["T"].append(f"{key}_{'ACGT'[nt]} {t.cell(p, 1 + nt)}")
+            lines["G"].append(f"{key}_{'ACGT'[nt]} {t.cell(p, 5 + nt)}")
+    ours = "".join(f"{tag} {l}\n" for tag in "RDTG" for l in sorted(lines[tag])).encode()
+    dig = _vc_digests()
+    assert (hashlib.sha256(ours).hexdigest(), len(ours.splitlines())) == dig[f"{name}.maps"]
+    if os.path.exists(f"{G}/vc_ref/{name}.maps.gz"):
+        assert ours == gzip.open(f"{G}/vc_ref/{name}.maps.gz").read()
+    vcf = (tmp_path / "dummy.vcf").read_bytes()
+    assert (hashlib.sha256(vcf).hexdigest(), len(vcf.splitlines())) == dig[f"{name}.vcf"]
+    # the numbers: strtof of the two halves of the reference's cell (sscanf "%[^_]_%[^_]", VC:886-890)
+    step = max(1, t.P // 3000)
+    for p in range(0, t.P, step):
+        for nt in range(4):
+            a, b = t.cell(p, 1 + nt).split("_")[:2]
+            assert t.thr[0, nt, p].view(np.int32) == _strtof(a) and t.thr[1, nt, p].view(np.int32) == _strtof(b)
+
+
 def test_error_table_reader_round_trip(tmp_path):
-    """VC's storeInputFile view of a table == the oracle's finalize thr (text round trip, 0.01 substitution)."""
+    """The same reader against the ORACLE's finalize (text round trip, 0.01 substitution): a self-consistency check beside
+    the reference pin above."""
     d = f"{G}/toy_subset"
     co = HostCohort(f"{d}/panel.bed", f"{d}/NORMAL", refbases_file=f"{d}/refbases.txt")
     acc, fin, _ = oracle_table(co, 0.002, 100, tmp_path, "rt.txt")
@@ -80,6 +157,38 @@ def test_error_table_reader_round_trip(tmp_path):
         m = co.ref_code != nt  # the ref cell is "-2_-2", never read by the caller
         assert np.array_equal(thr[:, nt][:, m].view(np.int32), fin["thr"][:, nt][:, m].view(np.int32))
         assert (thr[:, nt][:, ~m] == -2).all()
+
+
+@pytest.mark.parametrize("name", list(VC_TABLES))
+def test_sequence_context_against_the_reference_functions(tmp_path, name):
+    """f3's context columns, reference-pinned: 10-mer down / up and the homopolymer flag of every table position x 4
+    substituted bases == the reference's own find_kmer_down / find_kmer_up / homopolymerTest (VC:3307-3718) called the
+    way callVariants calls them (VC:964-965, 1017)."""
+    from amplisolve_amd.hostio import ErrorTable
+
+    t = ErrorTable(_vc_table(name, tmp_path))
+    want = gzip.open(f"{G}/vc_ref/{name}.context.gz").read().decode().splitlines()
+    assert len(want) == t.P == _vc_digests()[f"{name}.context"][1]
+    flagged = 0
+    for p, w in enumerate(want):
+        f = w.split(" ")
+        c, x = t.key(p)
+        assert (f[0], f[1], f[2]) == ("C", c, str(x))
+        for i, sub in enumerate("ACGT"):
+            down, up, flag = t.context(p, sub)
+            assert (down, up, str(flag)) == (f[3], f[4], f[5 + i]), (w, sub)
+            flagged += flag
+    if name == "context_edge":
+        assert flagged > 250  # the runs around the 18-of-21 decision are there
+    if name == "toy_full_0.0020":
+        assert flagged > 0
+
+
+def test_tumour_visit_order_against_the_reference(tmp_path):
+    """a1, VC twin (VC:387-394, 580-627): the order callVariants visits the tumour files in (VC:672) is the iteration order
+    of the reference's own TumourFileList_Hash for the same directory literal."""
+    want = [l.split("\t")[0] for l in open(f"{G}/vc_ref/toy_subset_TUMOUR.order").read().splitlines()]
+    assert sample_order(f"{G}/toy_subset/TUMOUR") == want and sorted(want) == ["T1", "T2", "T3"]
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/Toy_data"), reason="full Toy_data only exists in the build container")
