@@ -55,6 +55,8 @@ HIP_SYMBOLS = {
     "ampli_stream": (vp, [vp]),
     "ampli_pinned_alloc": (C.c_int, [sz, C.POINTER(vp)]),
     "ampli_pinned_free": (C.c_int, [vp]),
+    "ampli_host_register": (C.c_int, [vp, vp, C.c_size_t]),
+    "ampli_host_unregister": (C.c_int, [vp]),
     "ampli_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
     "ampli_dev_free": (C.c_int, [vp, vp]),
     "ampli_copy_h2d": (C.c_int, [vp, vp, vp, sz]),

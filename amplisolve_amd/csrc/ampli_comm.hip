@@ -157,6 +157,18 @@ extern "C" int ampli_comm_create(ampli_ctx *ctx, int32_t rank, int32_t world, co
             }
             if (!got) usleep(20000);
         }
+        if (got) {
+            // the file may be a dead run's that rank 0 is about to replace (it unlinks and rewrites on entry): look once more
+            // a moment later and take the newer record
+            usleep(250000);
+            IdFile again;
+            FILE *f = fopen(path.c_str(), "rb");
+            if (f) {
+                const bool whole = fread(&again, 1, sizeof again, f) == sizeof again;
+                fclose(f);
+                if (whole && memcmp(again.magic, "AMPLRCC2", 8) == 0 && again.world == world && again.nonce == nonce && again.written_at >= rec.written_at) rec = again;
+            }
+        }
         if (!got)
             return fail(ctx, AMPLI_E_HIP, ("timed out waiting for rank 0's id file " + path + (rejected.empty() ? "" : " (a file is there but was rejected: " + rejected + ")")).c_str());
     }
@@ -179,7 +191,7 @@ extern "C" int ampli_comm_create(ampli_ctx *ctx, int32_t rank, int32_t world, co
         if (!job->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return job->done; })) {
             delete c;
             if (rank == 0) (void)unlink(path.c_str());
-            return fail(ctx, AMPLI_E_HIP, ("ncclCommInitRank did not complete within " + std::to_string(timeout_s) + " s (AMPLISOLVE_RCCL_TIMEOUT): a rank is missing, or the id file " + path +
+            return fail(ctx, AMPLI_E_COMM_TIMEOUT, ("ncclCommInitRank did not complete within " + std::to_string(timeout_s) + " s (AMPLISOLVE_RCCL_TIMEOUT): a rank is missing, or the id file " + path +
                                            " is not this job's; the process should end now").c_str());
         }
         if (job->rc != ncclSuccess) {

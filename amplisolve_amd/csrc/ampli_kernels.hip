@@ -41,6 +41,7 @@ extern "C" const char *ampli_strerror(int code)
     case AMPLI_E_ENVELOPE: return "accumulators left the exactness envelope";
     case AMPLI_E_CAPACITY: return "call list capacity exceeded";
     case AMPLI_E_RANGE: return "count outside the integer envelope (>= 2^24)";
+    case AMPLI_E_COMM_TIMEOUT: return "RCCL communicator start-up timed out (the process must end)";
     default: return "unknown error";
     }
 }
@@ -203,6 +204,14 @@ extern "C" int ampli_pinned_alloc(size_t bytes, void **out)
     return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? AMPLI_OK : AMPLI_E_NOMEM;
 }
 extern "C" int ampli_pinned_free(void *p) { return hipHostFree(p) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP; }
+// pin memory the caller already owns and has filled (the command lines' parsers start before the runtime is up)
+extern "C" int ampli_host_register(ampli_ctx *ctx, void *p, size_t bytes)
+{
+    if (!p || !bytes) return AMPLI_E_INVALID;
+    if (ctx && hipSetDevice(ctx->device) != hipSuccess) return AMPLI_E_HIP; // the calling thread may not be the one that made the context
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? AMPLI_OK : AMPLI_E_NOMEM;
+}
+extern "C" int ampli_host_unregister(void *p) { return hipHostUnregister(p) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP; }
 
 extern "C" int ampli_dev_alloc(ampli_ctx *ctx, size_t bytes, void **d_out)
 {

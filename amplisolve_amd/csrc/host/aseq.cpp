@@ -274,8 +274,9 @@ void parse_file(const Panel &panel, const std::string &path, int layout, char *d
     close(fd);
 }
 
-void *host_alloc(size_t bytes, bool &pinned)
+void *host_alloc(size_t bytes, bool &pinned, bool critical = true)
 {
+    PhaseClock::Scope sc("pinned_alloc", critical);
     const HipApi *api = hip_api();
     void *mem = nullptr;
     if (api && api->device_count() > 0 && api->pinned_alloc(bytes ? bytes : 32, &mem) == AMPLI_OK) { pinned = true; return mem; }
@@ -291,6 +292,28 @@ void host_free(void *p, bool pinned)
     else free(p);
 }
 
+// the ring's buffers: plain page-aligned memory (2 MiB aligned so the kernel may back it with huge pages); no HIP call
+constexpr size_t kBufAlign = 2u << 20;
+void *ring_alloc(size_t &bytes)
+{
+    bytes = (std::max<size_t>(bytes, 1) + kBufAlign - 1) / kBufAlign * kBufAlign;
+    void *p = aligned_alloc(kBufAlign, bytes);
+    if (p) madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
+}
+
+void ring_free(void *&p, bool &pinned)
+{
+    if (!p) return;
+    if (pinned) {
+        PhaseClock::Scope sc("host_unregister", false);
+        if (const HipApi *api = hip_api()) api->host_unregister(p);
+    }
+    free(p);
+    p = nullptr;
+    pinned = false;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -299,8 +322,17 @@ void host_free(void *p, bool pinned)
 // ---------------------------------------------------------------------------------------------------------
 Chunk::~Chunk()
 {
-    host_free(prim, prim_pinned);
-    host_free(ext, ext_pinned);
+    ring_free(prim, prim_pinned);
+    ring_free(ext, ext_pinned);
+}
+
+void Chunk::pin(ampli_ctx *ctx)
+{
+    const HipApi *api = hip_api();
+    if (!api) return;
+    PhaseClock::Scope sc("host_register");
+    if (prim && !prim_pinned && api->host_register(ctx, prim, prim_cap) == AMPLI_OK) prim_pinned = true;
+    if (ext && !ext_pinned && api->host_register(ctx, ext, ext_cap) == AMPLI_OK) ext_pinned = true;
 }
 
 struct ChunkStream::Impl {
@@ -342,10 +374,9 @@ struct ChunkStream::Impl {
             res.assign((size_t)n, FileResult());
             const size_t rb = record_bytes(layout);
             if ((size_t)n * (size_t)P * rb > c.prim_cap) { // the buffers are sized for the narrowest layout; a wider chunk grows its own
-                host_free(c.prim, c.prim_pinned);
-                c.prim = nullptr;
+                ring_free(c.prim, c.prim_pinned);
                 c.prim_cap = (size_t)per_chunk * (size_t)P * rb;
-                c.prim = host_alloc(c.prim_cap, c.prim_pinned);
+                c.prim = ring_alloc(c.prim_cap);
                 if (!c.prim) throw Error{AMPLI_E_NOMEM, "cannot allocate the record buffers"};
             }
             if (keep_line) c.line_prim.assign((size_t)n * P, -1);
@@ -390,10 +421,9 @@ struct ChunkStream::Impl {
         const size_t rb = record_bytes(layout);
         const size_t need = (size_t)n * (size_t)c.E * rb;
         if (need > c.ext_cap) {
-            host_free(c.ext, c.ext_pinned);
-            c.ext = nullptr;
+            ring_free(c.ext, c.ext_pinned);
             c.ext_cap = need + need / 2 + 4096;
-            c.ext = host_alloc(c.ext_cap, c.ext_pinned);
+            c.ext = ring_alloc(c.ext_cap);
             if (!c.ext) throw Error{AMPLI_E_NOMEM, "cannot allocate the extra-occurrence records"};
         }
         if (c.E) fill_absent(layout, (char *)c.ext, (size_t)n * (size_t)c.E);
@@ -484,7 +514,7 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
         std::unique_ptr<Chunk> c(new Chunk());
         c->slot = i;
         c->prim_cap = (size_t)per * (size_t)P * record_bytes(im->start_layout); // a chunk that needs wider records grows its buffer (fill)
-        c->prim = host_alloc(c->prim_cap, c->prim_pinned);
+        c->prim = ring_alloc(c->prim_cap);
         if (!c->prim) throw Error{AMPLI_E_NOMEM, "cannot allocate the record buffers"};
         im->slots.push_back(std::move(c));
         im->free_slots.push_back(i);
@@ -492,7 +522,7 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
     im->producer = std::thread([this] { im->run(); });
 }
 
-ChunkStream::~ChunkStream()
+void ChunkStream::shutdown()
 {
     {
         std::lock_guard<std::mutex> lk(im->mu);
@@ -500,6 +530,12 @@ ChunkStream::~ChunkStream()
     }
     im->cv.notify_all();
     if (im->producer.joinable()) im->producer.join();
+    im->slots.clear();
+}
+
+ChunkStream::~ChunkStream()
+{
+    shutdown();
     delete im;
 }
 

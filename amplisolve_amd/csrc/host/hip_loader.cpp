@@ -47,6 +47,7 @@ static void load()
     BIND(abi_version, "ampli_abi_version") BIND(strerror_, "ampli_strerror") BIND(device_count, "ampli_device_count")
     BIND(ctx_create, "ampli_ctx_create") BIND(ctx_destroy, "ampli_ctx_destroy") BIND(last_error, "ampli_last_error")
     BIND(sync, "ampli_sync") BIND(pinned_alloc, "ampli_pinned_alloc") BIND(pinned_free, "ampli_pinned_free")
+    BIND(host_register, "ampli_host_register") BIND(host_unregister, "ampli_host_unregister")
     BIND(dev_alloc, "ampli_dev_alloc") BIND(dev_free, "ampli_dev_free") BIND(copy_h2d, "ampli_copy_h2d")
     BIND(copy_d2h, "ampli_copy_d2h") BIND(memset_d, "ampli_memset_d") BIND(acc_bytes, "ampli_acc_bytes")
     BIND(acc_bind, "ampli_acc_bind") BIND(error_reduce, "ampli_error_reduce") BIND(error_finalize, "ampli_error_finalize") BIND(error_estimate, "ampli_error_estimate")

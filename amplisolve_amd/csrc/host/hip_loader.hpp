@@ -18,6 +18,8 @@ struct HipApi {
     int (*sync)(ampli_ctx *);
     int (*pinned_alloc)(size_t, void **);
     int (*pinned_free)(void *);
+    int (*host_register)(ampli_ctx *, void *, size_t);
+    int (*host_unregister)(void *);
     int (*dev_alloc)(ampli_ctx *, size_t, void **);
     int (*dev_free)(ampli_ctx *, void *);
     int (*copy_h2d)(ampli_ctx *, void *, const void *, size_t);

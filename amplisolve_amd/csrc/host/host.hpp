@@ -5,6 +5,7 @@
 // lives here.  EE:n / VC:n cite /root/reference/source_codes/AmpliSolve{ErrorEstimation,VariantCalling}.cpp.
 #pragma once
 #include <cstdint>
+#include <iosfwd>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -82,12 +83,13 @@ struct Chunk {
     bool last = false;
     int layout = AMPLI_RECORDS_U24;
     int64_t P = 0, E = 0;
-    void *prim = nullptr;          // [n][P] records, pinned when a GPU is present
-    size_t prim_cap = 0;
+    void *prim = nullptr;          // [n][P] records; page-aligned host memory the parsers fill BEFORE the HIP runtime is up,
+    size_t prim_cap = 0;           // pinned late (pin(): hipHostRegister) by the consumer once there is a context
     bool prim_pinned = false;
     void *ext = nullptr;           // [n][E] records
     size_t ext_cap = 0;
     bool ext_pinned = false;
+    void pin(ampli_ctx *ctx);      // register prim / ext with the runtime if they are not yet (no-op without the HIP library)
     std::vector<uint32_t> dup_off; // [P+1]
     std::vector<uint32_t> ext_pos; // [E]
     std::vector<int32_t> line_prim, line_ext; // [n][P], [n][E] data-line index inside the sample's file (-1 absent); variant calling only
@@ -99,8 +101,9 @@ struct Chunk {
     ~Chunk();
 };
 
-// The cohort as a stream of chunks: a producer thread (with n_threads parser workers) fills a small ring of pinned
-// buffers ahead of the consumer, so parsing of chunk k+1 overlaps the upload and the kernels of chunk k and the host
+// The cohort as a stream of chunks: a producer thread (with n_threads parser workers) fills a small ring of page-aligned
+// buffers ahead of the consumer (they need no HIP call, so parsing starts while the runtime is still coming up; the
+// consumer pins a buffer the first time it uploads from it), so parsing of chunk k+1 overlaps the upload and the kernels of chunk k and the host
 // never holds more than n_slots chunks (replaces the parse loops of EE:1100-1149 / VC:699-752).
 class ChunkStream {
 public:
@@ -111,6 +114,7 @@ public:
     ChunkStream &operator=(const ChunkStream &) = delete;
     Chunk *next();            // next chunk in order, nullptr after the last; rethrows the producer's Error
     void release(Chunk *c);   // the chunk's buffers may be refilled
+    void shutdown();          // stop the producer and free the ring now (the destructor does the same)
     int samples_per_chunk() const;
     int chunks() const;
     double parse_seconds() const; // producer time spent parsing so far
@@ -119,6 +123,22 @@ private:
     Impl *im;
 };
 
+// ---- pipeline.cpp: where a command line's wall time goes (printed with AMPLISOLVE_TIMING) ----
+// Named spans, summed per name, from any thread.  `critical` spans lie on the main thread's path, so they add up to the
+// wall time; the others (side-thread context start-up, parser threads) are reported as overlapped work beside them.
+struct PhaseClock {
+    static double now();                                   // seconds, steady clock
+    static void add(const char *name, double seconds, bool critical);
+    struct Scope {
+        const char *name;
+        bool critical;
+        double t0;
+        Scope(const char *n, bool c = true) : name(n), critical(c), t0(now()) {}
+        ~Scope() { add(name, now() - t0, critical); }
+    };
+    static void reset();
+    static void report(std::ostream &os, double wall);     // "TIMING2 <name> <seconds> critical|overlapped" lines + the unattributed rest
+};
 // ---- panel.cpp ----
 void panel_from_bed(const std::string &bed_path, Panel &out);                   // throws Error
 void panel_load_refbases_file(Panel &p, const std::string &path);               // chrom pos base per line (EE:963)
@@ -175,6 +195,10 @@ struct CcArgs {
 int run_compute_counts(const CcArgs &a);
 // BGZF + BAM structure only (no GPU): stats[4] = alignment records, uncompressed bytes, references, malformed records
 void bam_scan(const std::string &bam, int n_threads, int64_t stats[4]);
+// End of a command line: all outputs are written and closed.  Flushes stdio / iostreams and leaves with _exit(status), i.e.
+// without the static destructors and atexit handlers of the HIP runtime (queue / signal / pool teardown that only serves a
+// process that lives on; the driver reclaims everything at exit either way).  AMPLISOLVE_EXIT=orderly returns instead.
+void finish_process(int status);
 int run_error_estimation(const EeArgs &a);
 int run_variant_calling(const VcArgs &a);
 // ---- annotate.cpp ----

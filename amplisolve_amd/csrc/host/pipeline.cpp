@@ -4,6 +4,7 @@
 // Parsing / formatting happen here; sums, rates, p-values and the call gate come from libamplisolve_hip.so.
 #include <sys/stat.h>
 #include <sys/types.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <chrono>
@@ -15,6 +16,8 @@
 #include <fstream>
 #include <iomanip>
 #include <iostream>
+#include <memory>
+#include <mutex>
 #include <sstream>
 #include <thread>
 
@@ -22,6 +25,36 @@
 #include "host.hpp"
 
 namespace ampli {
+
+// ---- PhaseClock ----
+namespace {
+struct PhaseEntry { std::string name; double s; bool critical; };
+std::mutex g_phase_mu;
+std::vector<PhaseEntry> g_phases;
+} // namespace
+double PhaseClock::now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void PhaseClock::add(const char *name, double seconds, bool critical)
+{
+    std::lock_guard<std::mutex> lk(g_phase_mu);
+    for (auto &e : g_phases)
+        if (e.name == name && e.critical == critical) { e.s += seconds; return; }
+    g_phases.push_back(PhaseEntry{name, seconds, critical});
+}
+void PhaseClock::reset()
+{
+    std::lock_guard<std::mutex> lk(g_phase_mu);
+    g_phases.clear();
+}
+void PhaseClock::report(std::ostream &os, double wall)
+{
+    std::lock_guard<std::mutex> lk(g_phase_mu);
+    double sum = 0;
+    for (auto &e : g_phases) {
+        os << "TIMING2 " << e.name << " " << e.s << (e.critical ? " critical" : " overlapped") << "\n";
+        if (e.critical) sum += e.s;
+    }
+    os << "TIMING2 unattributed " << wall - sum << " critical\nTIMING2 wall_in_main " << wall << " total" << std::endl;
+}
 
 namespace {
 
@@ -36,7 +69,7 @@ void mkdir_p(const std::string &path) // generateFolder: `mkdir -p` (EE:3079-308
     }
 }
 
-double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+double now_s() { return PhaseClock::now(); }
 
 struct Dev {
     const HipApi *api = nullptr;
@@ -45,6 +78,7 @@ struct Dev {
     ~Dev()
     {
         if (ctx) {
+            PhaseClock::Scope sc("device_teardown");
             for (void *p : allocs) api->dev_free(ctx, p);
             api->ctx_destroy(ctx);
         }
@@ -54,18 +88,27 @@ struct Dev {
         if (rc != AMPLI_OK)
             throw Error{rc, std::string(what) + ": " + api->strerror_(rc) + (ctx ? std::string(" -- ") + api->last_error(ctx) : "")};
     }
+    bool side = false; // opened on a side thread: its start-up spans are overlapped work, not the main thread's path
     void open()
     {
         std::string why;
-        api = hip_api(&why);
+        {
+            PhaseClock::Scope sc("hip_library_load", !side); // dlopen of libamplisolve_hip.so: pulls in the HIP runtime, registers the code object
+            api = hip_api(&why);
+        }
         if (!api) throw Error{AMPLI_E_HIP, "libamplisolve_hip.so could not be loaded (" + why + "); there is no CPU fallback"};
-        if (api->device_count() <= 0) throw Error{AMPLI_E_HIP, "no MI355X visible; there is no CPU fallback"};
+        {
+            PhaseClock::Scope sc("runtime_init", !side); // the first HIP call of the process: HSA / driver start-up
+            if (api->device_count() <= 0) throw Error{AMPLI_E_HIP, "no MI355X visible; there is no CPU fallback"};
+        }
         int dev = 0;
         if (const char *e = getenv("AMPLISOLVE_DEVICE")) dev = atoi(e);
+        PhaseClock::Scope sc("context_create", !side); // hipSetDevice + properties + the first hipMalloc / hipMemset
         check(api->ctx_create(dev, nullptr, &ctx), "ampli_ctx_create");
     }
     template <class T> T *alloc(size_t n)
     {
+        PhaseClock::Scope sc("device_alloc");
         void *p = nullptr;
         check(api->dev_alloc(ctx, n * sizeof(T), &p), "ampli_dev_alloc");
         allocs.push_back(p);
@@ -73,18 +116,32 @@ struct Dev {
     }
     void free(void *p)
     {
+        PhaseClock::Scope sc("device_alloc");
         for (auto it = allocs.begin(); it != allocs.end(); ++it)
             if (*it == p) { allocs.erase(it); break; }
         check(api->dev_free(ctx, p), "ampli_dev_free");
     }
+    void h2d(void *d, const void *src, size_t bytes)
+    {
+        PhaseClock::Scope sc("h2d_enqueue");
+        check(api->copy_h2d(ctx, d, src, bytes), "ampli_copy_h2d");
+    }
     template <class T> T *upload(const T *src, size_t n)
     {
         T *d = alloc<T>(n ? n : 1);
-        if (n) check(api->copy_h2d(ctx, d, src, n * sizeof(T)), "ampli_copy_h2d");
+        if (n) h2d(d, src, n * sizeof(T));
         return d;
     }
-    template <class T> void download(T *dst, const T *d, size_t n) { check(api->copy_d2h(ctx, dst, d, n * sizeof(T)), "ampli_copy_d2h"); }
-    void sync() { check(api->sync(ctx), "ampli_sync"); }
+    template <class T> void download(T *dst, const T *d, size_t n)
+    {
+        PhaseClock::Scope sc("d2h");
+        check(api->copy_d2h(ctx, dst, d, n * sizeof(T)), "ampli_copy_d2h");
+    }
+    void sync()
+    {
+        PhaseClock::Scope sc("device_wait");
+        check(api->sync(ctx), "ampli_sync");
+    }
 };
 
 // a device buffer that only ever grows (one per ring slot and kind)
@@ -117,6 +174,7 @@ struct DevAsync {
     void start()
     {
         started = true;
+        dev.side = true;
         th = std::thread([this] {
             try {
                 dev.open();
@@ -128,7 +186,10 @@ struct DevAsync {
     Dev &get() // the opened context; rethrows what open() threw (no device, no library: there is no CPU fallback)
     {
         if (!started) start();
-        if (th.joinable()) th.join();
+        {
+            PhaseClock::Scope sc("wait_for_context"); // what of the start-up the panel / table parsing did not hide
+            if (th.joinable()) th.join();
+        }
         if (ex) std::rethrow_exception(ex);
         return dev;
     }
@@ -147,13 +208,27 @@ size_t chunk_bytes_setting()
     return mb << 20;
 }
 
-// upload one chunk into its ring slot and describe it for the kernels
-ampli_records upload_chunk(Dev &dev, DevSlot &ds, const Chunk &c, bool for_calling)
+// AMPLISOLVE_PIN: how a ring buffer reaches the device.  "register" (default): the parsers fill plain page-aligned memory
+// -- they start before the HIP runtime is up -- and the buffer is pinned (hipHostRegister, ~6 ms per 128 MB) the first
+// time it is uploaded from; "none": never pinned, the runtime stages the copy.  (Round 3 allocated the ring with
+// hipHostMalloc: 23 ms per 128 MB up front, after the context was up, and 15 ms per 128 MB to free -- tools/micro/init_probe.cpp.)
+bool pin_late()
 {
+    static const bool v = [] {
+        const char *e = getenv("AMPLISOLVE_PIN");
+        return !(e && std::string(e) == "none");
+    }();
+    return v;
+}
+
+// upload one chunk into its ring slot and describe it for the kernels
+ampli_records upload_chunk(Dev &dev, DevSlot &ds, Chunk &c, bool for_calling)
+{
+    if (pin_late()) c.pin(dev.ctx);
     const size_t rb = record_bytes(c.layout);
     const size_t pb = (size_t)c.n * (size_t)c.P * rb, eb = (size_t)c.n * (size_t)c.E * rb;
     void *d_prim = ds.prim.ensure(dev, pb);
-    dev.check(dev.api->copy_h2d(dev.ctx, d_prim, c.prim, pb), "ampli_copy_h2d");
+    dev.h2d(d_prim, c.prim, pb);
     ampli_records r;
     memset(&r, 0, sizeof r);
     r.recs = d_prim;
@@ -163,12 +238,12 @@ ampli_records upload_chunk(Dev &dev, DevSlot &ds, const Chunk &c, bool for_calli
     r.E = c.E;
     if (c.E > 0) {
         void *d_ext = ds.ext.ensure(dev, eb);
-        dev.check(dev.api->copy_h2d(dev.ctx, d_ext, c.ext, eb), "ampli_copy_h2d");
+        dev.h2d(d_ext, c.ext, eb);
         r.ext = d_ext;
         r.ext_stride = c.E;
         const std::vector<uint32_t> &aux = for_calling ? c.ext_pos : c.dup_off;
         void *d_aux = ds.aux.ensure(dev, aux.size() * sizeof(uint32_t));
-        dev.check(dev.api->copy_h2d(dev.ctx, d_aux, aux.data(), aux.size() * sizeof(uint32_t)), "ampli_copy_h2d");
+        dev.h2d(d_aux, aux.data(), aux.size() * sizeof(uint32_t));
         if (for_calling) r.ext_pos = (const uint32_t *)d_aux;
         else r.dup_off = (const uint32_t *)d_aux;
     }
@@ -181,11 +256,11 @@ ampli_records upload_chunk(Dev &dev, DevSlot &ds, const Chunk &c, bool for_calli
             else rde[(size_t)x.sample * c.E + (x.record - c.P)] = x.rd;
         }
         void *d_rd = ds.rd.ensure(dev, rd.size() * sizeof(int32_t));
-        dev.check(dev.api->copy_h2d(dev.ctx, d_rd, rd.data(), rd.size() * sizeof(int32_t)), "ampli_copy_h2d");
+        dev.h2d(d_rd, rd.data(), rd.size() * sizeof(int32_t));
         r.rd = (const int32_t *)d_rd;
         if (c.E > 0) {
             void *d_rde = ds.rd_ext.ensure(dev, rde.size() * sizeof(int32_t));
-            dev.check(dev.api->copy_h2d(dev.ctx, d_rde, rde.data(), rde.size() * sizeof(int32_t)), "ampli_copy_h2d");
+            dev.h2d(d_rde, rde.data(), rde.size() * sizeof(int32_t));
             r.rd_ext = (const int32_t *)d_rde;
         }
         dev.sync(); // the host vectors go out of scope
@@ -230,7 +305,18 @@ struct NativeShard {
         }
         if (nd.id_file.empty()) throw Error{AMPLI_E_INVALID, "multi-GPU run: AMPLISOLVE_ID_FILE (a path every process can see) is not set"};
         dev.open();
-        dev.check(dev.api->comm_create(dev.ctx, nd.rank, nd.world, nd.id_file.c_str(), nd.timeout_s, &comm), "ampli_comm_create");
+        const int crc = dev.api->comm_create(dev.ctx, nd.rank, nd.world, nd.id_file.c_str(), nd.timeout_s, &comm);
+        if (crc == AMPLI_E_COMM_TIMEOUT) {
+            // a detached helper thread is still inside ncclCommInitRank on this device: unwinding through ~Dev (hipFree,
+            // context teardown) or exit()'s static destructors beside it can hang or crash.  Say why and leave at once.
+            std::cout << "\t\t\nSomething went wrong: ampli_comm_create: " << dev.api->last_error(dev.ctx)
+                      << "\n                                        Sorry but Amplisolve cannot continue..." << std::endl;
+            std::cout.flush();
+            std::cerr.flush();
+            fflush(nullptr);
+            _exit(1);
+        }
+        dev.check(crc, "ampli_comm_create");
         dev.check(dev.api->comm_barrier(comm), "ampli_comm_barrier"); // every rank has read the id
         if (nd.rank == 0) std::remove(nd.id_file.c_str());
     }
@@ -301,6 +387,16 @@ struct NativeShard {
 const char *kLine = "************************************************************************************************************************************";
 
 } // namespace
+
+void finish_process(int status)
+{
+    const char *e = getenv("AMPLISOLVE_EXIT");
+    if (e && std::string(e) == "orderly") return;
+    std::cout.flush();
+    std::cerr.flush();
+    fflush(nullptr);
+    _exit(status);
+}
 
 NativeDist native_dist_from_env(const std::string &output_dir)
 {
@@ -377,10 +473,13 @@ int run_error_estimation(const EeArgs &a)
 
         double t0 = now_s();
         Panel panel;
-        panel_from_bed(a.panel_design, panel);
-        if (!a.refbases_file.empty()) panel_load_refbases_file(panel, a.refbases_file);
-        else panel_load_fasta(panel, a.reference_genome);
-        if (writer) panel_write_interm_files(panel, interm, seed);
+        {
+            PhaseClock::Scope sc("panel");
+            panel_from_bed(a.panel_design, panel);
+            if (!a.refbases_file.empty()) panel_load_refbases_file(panel, a.refbases_file);
+            else panel_load_fasta(panel, a.reference_genome);
+            if (writer) panel_write_interm_files(panel, interm, seed);
+        }
         std::cout << "\nRunning function generateReferenceBases: Reference bases and amplicon duplicated positions have generated"
                   << "\n\t\t --> Parsed in total " << panel.rows.size() << " amplicons and annotated " << panel.walk.size() << " positions." << std::endl;
         std::cout << "Running function storeReference: panel reference bases stored with success " << panel.P() << std::endl;
@@ -400,7 +499,11 @@ int run_error_estimation(const EeArgs &a)
         const std::string list_name = interm + "/" + std::to_string(seed) + "_germline_count_list_original.txt"; // EE:442
         int threads = 0;
         if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
-        auto files = list_count_files(a.germline_dir, writer ? list_name : std::string());
+        std::vector<std::pair<std::string, std::string>> files;
+        {
+            PhaseClock::Scope sc("list_files");
+            files = list_count_files(a.germline_dir, writer ? list_name : std::string());
+        }
         const int total_samples = (int)files.size();
         int first_sample = 0;
         if (sh) files = shard_of_files(files, sh->index, sh->count, &first_sample);
@@ -409,6 +512,9 @@ int run_error_estimation(const EeArgs &a)
         if (sh) std::cout << "\tshard " << sh->index + 1 << "/" << sh->count << ": samples " << first_sample + 1 << ".." << first_sample + S << std::endl;
         std::cout << "Running function storeGermlineStatistics:" << std::endl;
 
+        // the parsers start NOW, into plain memory, while the runtime is still coming up on the side thread
+        std::unique_ptr<ChunkStream> first_stream;
+        if (S > 0) first_stream.reset(new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), 4));
         Dev &dev = dev_async.get();
         const int64_t P = panel.P();
         float *d_rate = dev.alloc<float>((size_t)P * 8), *d_germ = dev.alloc<float>((size_t)P * 4);
@@ -422,7 +528,7 @@ int run_error_estimation(const EeArgs &a)
         void *ev = nullptr;
         dev.check(dev.api->event_create(&ev), "ampli_event_create");
         struct EvGuard { const HipApi *api; void *ev; ~EvGuard() { if (ev) api->event_destroy(ev); } } evg{dev.api, ev};
-        DevSlot dslots[3];
+        DevSlot dslots[4];
         int64_t n_lines = 0;
         double parse_s = 0, wait_s = 0, rec_bytes_up = 0;
         int chunks_done = 0;
@@ -435,18 +541,29 @@ int run_error_estimation(const EeArgs &a)
             n_lines = 0;
             rec_bytes_up = 0;
             if (S > 0) {
-                ChunkStream cs(panel, files, threads, false, chunk_bytes_setting(), 3);
-                for (Chunk *c; (c = cs.next()) != nullptr;) {
+                std::unique_ptr<ChunkStream> own(attempt == 0 ? first_stream.release() : new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), 4));
+                ChunkStream &cs = *own;
+                auto next_chunk = [&] {
+                    PhaseClock::Scope sc("wait_for_parser");
+                    return cs.next();
+                };
+                for (Chunk *c; (c = next_chunk()) != nullptr;) {
                     if (attempt == 0) // the reference's own message, once per offending line (EE:1178-1181)
                         for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl;
                     const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, false);
                     const bool fuse = c->last && !sh; // one device holds the whole panel: finalize in the last chunk's launch
-                    dev.check(dev.api->error_reduce_records(dev.ctx, &r, P, first_sample + c->first, C_value, cov, &acc, chunks_done > 0 ? 1 : 0,
-                                                            fuse ? d_rate : nullptr, fuse ? d_code : nullptr, nullptr, fuse ? d_germ : nullptr,
-                                                            fuse ? d_gp : nullptr, fuse ? d_flags : nullptr), "ampli_error_reduce_records");
-                    dev.check(dev.api->event_record(dev.ctx, ev), "ampli_event_record");
+                    {
+                        PhaseClock::Scope sc(chunks_done == 0 && attempt == 0 ? "first_launch" : "launch"); // the first one loads the code object
+                        dev.check(dev.api->error_reduce_records(dev.ctx, &r, P, first_sample + c->first, C_value, cov, &acc, chunks_done > 0 ? 1 : 0,
+                                                                fuse ? d_rate : nullptr, fuse ? d_code : nullptr, nullptr, fuse ? d_germ : nullptr,
+                                                                fuse ? d_gp : nullptr, fuse ? d_flags : nullptr), "ampli_error_reduce_records");
+                        dev.check(dev.api->event_record(dev.ctx, ev), "ampli_event_record");
+                    }
                     const double w0 = now_s();
-                    dev.check(dev.api->event_sync(ev), "ampli_event_sync"); // the chunk's buffers are free again
+                    {
+                        PhaseClock::Scope sc("device_wait");
+                        dev.check(dev.api->event_sync(ev), "ampli_event_sync"); // the chunk's buffers are free again
+                    }
                     wait_s += now_s() - w0;
                     n_lines += c->n_lines;
                     rec_bytes_up += (double)c->n * (double)(P + c->E) * (double)record_bytes(c->layout);
@@ -456,6 +573,10 @@ int run_error_estimation(const EeArgs &a)
                     cs.release(c);
                 }
                 parse_s += cs.parse_seconds();
+                PhaseClock::add("parser_busy", cs.parse_seconds(), false);
+                const double d0 = now_s();
+                cs.shutdown(); // joins the producer and frees the ring here, where it can be timed
+                PhaseClock::add("stream_teardown", now_s() - d0, true);
             }
             int32_t kflags = 0;
             dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
@@ -510,7 +631,10 @@ int run_error_estimation(const EeArgs &a)
         char name[64];
         snprintf(name, sizeof name, "positionSpecificNoise_%.4f.txt", (double)C_value); // EE:2556
         const std::string out = a.output_dir + "/" + name;
-        if (writer) write_error_table(panel, rate.data(), code.data(), germ.data(), gp.data(), out);
+        if (writer) {
+            PhaseClock::Scope sc("write_table");
+            write_error_table(panel, rate.data(), code.data(), germ.data(), gp.data(), out);
+        }
         if (sh) hook(sh->barrier(sh->user), "barrier");
         double t4 = now_s();
         std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
@@ -588,14 +712,21 @@ int run_variant_calling(const VcArgs &a)
         const double t0 = now_s();
         Panel panel;
         std::vector<float> thr;
-        panel_from_error_table(a.error_file, writer ? interm + "/dummyVCF_1.vcf" : std::string(), panel, thr); // VC:320
+        {
+            PhaseClock::Scope sc("read_table");
+            panel_from_error_table(a.error_file, writer ? interm + "/dummyVCF_1.vcf" : std::string(), panel, thr); // VC:320
+        }
         std::cout << "Running function storeInputFile: the error levels have stored with success " << panel.walk.size() << std::endl;
         srand((unsigned)time(nullptr));
         const int seed = rand() % 1000;
         const std::string list_name = interm + "/" + std::to_string(seed) + "_tumour_count_list_original.txt"; // VC:332
         int threads = 0;
         if (const char *e = getenv("AMPLISOLVE_THREADS")) threads = atoi(e);
-        auto files = list_count_files(a.tumour_dir, writer ? list_name : std::string());
+        std::vector<std::pair<std::string, std::string>> files;
+        {
+            PhaseClock::Scope sc("list_files");
+            files = list_count_files(a.tumour_dir, writer ? list_name : std::string());
+        }
         const int total_samples = (int)files.size();
         int first_sample = 0;
         if (sh) files = shard_of_files(files, sh->index, sh->count, &first_sample);
@@ -611,15 +742,20 @@ int run_variant_calling(const VcArgs &a)
         double parse_s = 0, rec_bytes_up = 0;
         int chunks_done = 0;
         if (T > 0 || !sh) { // a shard of a multi-process run may hold no tumour file
+            // tumour files are independent given the error table: they stream through in chunks (parsing of the next
+            // chunks overlaps upload + kernels of this one); only the emitted calls come back.  The parsers start before
+            // the context is waited for.
+            ChunkStream cs(panel, files, threads, true, chunk_bytes_setting(), 4);
             Dev &dev = dev_async.get();
             float *d_thr = dev.upload(thr.data(), thr.size());
             uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
             unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
-            DevSlot dslots[3];
-            // tumour files are independent given the error table: they stream through in chunks (parsing of the next
-            // chunks overlaps upload + kernels of this one); only the emitted calls come back
-            ChunkStream cs(panel, files, threads, true, chunk_bytes_setting(), 3);
-            for (Chunk *c; (c = cs.next()) != nullptr;) {
+            DevSlot dslots[4];
+            auto next_chunk = [&] {
+                PhaseClock::Scope sc("wait_for_parser");
+                return cs.next();
+            };
+            for (Chunk *c; (c = next_chunk()) != nullptr;) {
                 for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl; // VC:762-765
                 const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, true);
                 const int64_t R = P + c->E;
@@ -633,11 +769,17 @@ int run_variant_calling(const VcArgs &a)
                     const int64_t per = cap / AMPLI_CALL_SHARDS;
                     if (d_calls) dev.free(d_calls); // the previous attempt's list
                     d_calls = dev.alloc<ampli_call>((size_t)cap);
-                    dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
-                    dev.check(dev.api->poisson_call_records(dev.ctx, &r, P, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask, d_calls, cap, d_n,
-                                                            nullptr, nullptr), "ampli_poisson_call_records");
+                    {
+                        PhaseClock::Scope sc(chunks_done == 0 && attempt == 0 ? "first_launch" : "launch"); // the first one loads the code object
+                        dev.check(dev.api->memset_d(dev.ctx, d_n, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS), "memset");
+                        dev.check(dev.api->poisson_call_records(dev.ctx, &r, P, d_thr, d_ref, cov, AMPLI_POISSON_PREFILTER, d_mask, d_calls, cap, d_n,
+                                                                nullptr, nullptr), "ampli_poisson_call_records");
+                    }
                     int32_t kflags = 0;
-                    dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+                    {
+                        PhaseClock::Scope sc("device_wait");
+                        dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+                    }
                     if (kflags & AMPLI_FLAG_QUEUE_OVERFLOW) { // more survivors than the default queue holds: size it for the worst case
                         dev.check(dev.api->set_queue_items(dev.ctx, (int64_t)c->n * R * 3), "ampli_set_queue_items");
                         why = "prefilter queue still overflowing";
@@ -682,6 +824,10 @@ int run_variant_calling(const VcArgs &a)
                 cs.release(c);
             }
             parse_s = cs.parse_seconds();
+            PhaseClock::add("parser_busy", parse_s, false);
+            const double d0 = now_s();
+            cs.shutdown();
+            PhaseClock::add("stream_teardown", now_s() - d0, true);
         }
         const double t2 = now_s();
         // Calls within rounding of a gate.  The device forms Q in fp64 with ROCm's exp / log, the reference with glibc and an
@@ -801,6 +947,7 @@ int run_variant_calling(const VcArgs &a)
                 if (all.fail()) throw Error{AMPLI_E_INVALID, "could not write " + summary};
             }
         }
+        PhaseClock::add("annotate_and_write", now_s() - t2, true);
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING table " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done << " parse_busy "
                       << parse_s << " record_MB " << rec_bytes_up / 1e6 << " calls " << rows.size() << " guarded " << n_guarded << " dropped_by_guard " << n_dropped << "\nTIMING annotate+write " << now_s() - t2 << std::endl;

@@ -19,6 +19,7 @@ static std::string token(const char *arg, const char *key)
 
 int main(int argc, char **argv)
 {
+    const double t_main = ampli::PhaseClock::now();
     setlocale(LC_ALL, "");
     const bool strict = getenv("AMPLISOLVE_STRICT_EXIT") != nullptr;
     if (argc != 6) {
@@ -36,5 +37,8 @@ int main(int argc, char **argv)
     a.p_value = token(argv[5], "p_value");
     a.native = ampli::native_dist_from_env(a.output_dir); // AMPLISOLVE_WORLD_SIZE > 1: one shard of a one-process-per-GPU run (RCCL)
     const int rc = ampli::run_variant_calling(a);
-    return (strict || a.native.world > 1) ? (rc ? 1 : 0) : 0; // a failed shard must be visible to whatever launched the shards
+    if (getenv("AMPLISOLVE_TIMING")) ampli::PhaseClock::report(std::cerr, ampli::PhaseClock::now() - t_main);
+    const int status = (strict || a.native.world > 1) ? (rc ? 1 : 0) : 0; // a failed shard must be visible to whatever launched the shards
+    ampli::finish_process(status); // every file is written and closed: leave without the runtime's orderly teardown (AMPLISOLVE_EXIT=orderly keeps it)
+    return status;
 }

@@ -65,6 +65,9 @@ extern "C" {
 #define AMPLI_E_ENVELOPE (-4) /* double accumulators left the exactness envelope */
 #define AMPLI_E_CAPACITY (-5) /* compact call list overflowed; n_calls holds the needed size */
 #define AMPLI_E_RANGE (-6)    /* a count does not fit the kernels' integer envelope */
+#define AMPLI_E_COMM_TIMEOUT (-7) /* ampli_comm_create: ncclCommInitRank did not return in time.  A helper thread is still inside
+                                   * RCCL on this device: the process MUST end now -- print, flush, _exit(1); do not destroy the
+                                   * context, do not run static destructors, never re-exec */
 
 typedef struct ampli_ctx ampli_ctx;
 
@@ -96,6 +99,10 @@ void *ampli_stream(ampli_ctx *ctx);    /* the hipStream_t in use */
 /* memory plumbing */
 int ampli_pinned_alloc(size_t bytes, void **out);
 int ampli_pinned_free(void *p);
+/* pin (page-lock + map for the device) host memory the caller owns, e.g. a record buffer the parsers filled while the runtime
+ * was still starting; p / bytes page aligned; ctx (may be NULL) names the device.  ampli_host_unregister before the memory is freed. */
+int ampli_host_register(ampli_ctx *ctx, void *p, size_t bytes);
+int ampli_host_unregister(void *p);
 int ampli_dev_alloc(ampli_ctx *ctx, size_t bytes, void **d_out);
 int ampli_dev_free(ampli_ctx *ctx, void *d_p);
 int ampli_copy_h2d(ampli_ctx *ctx, void *d_dst, const void *src, size_t bytes); /* async */
@@ -386,7 +393,10 @@ int ampli_graph_destroy(void *graph_exec);
  * the launch's AMPLISOLVE_JOB_NONCE (optional; any integer the launcher gives every rank) and the time; the others wait up
  * to timeout_s for a file that carries THEIR world size and nonce and is not older than the job, and ncclCommInitRank
  * itself is bounded by timeout_s as well (RCCL has no timeout of its own): a missing rank or a stale file ends in
- * AMPLI_E_HIP with a message, never in a hang.  Collectives are enqueued on the context's
+ * AMPLI_E_HIP (no usable id file) or AMPLI_E_COMM_TIMEOUT (the init itself timed out: the caller must _exit, see the
+ * code's comment) with a message, never in a hang.  A rank above 0 reads the file once more 0.25 s after accepting it and
+ * takes the newer one, so a relaunch right after a crash does not pick up the dead run's id in the moment before rank 0
+ * replaces it (without a nonce that window cannot be closed completely: give every launch its AMPLISOLVE_JOB_NONCE).  Collectives are enqueued on the context's
  * stream; the *_i32 / *_i64 helpers take HOST values and synchronise.  Buffer shapes as in "Position-sliced merge".
  */
 typedef struct ampli_comm ampli_comm;
