@@ -176,6 +176,7 @@ HOST_SYMBOLS = {
     "ampli_host_compute_counts": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, i32, i32, i32, i32, C.POINTER(i64)]),
     "ampli_host_bam_scan": (C.c_int, [C.c_char_p, i32, C.POINTER(i64)]),
     "ampli_host_fisher": (C.c_double, [C.c_int] * 4),
+    "ampli_host_fisher_direct": (C.c_double, [C.c_int] * 4),
     "ampli_host_guard_score": (C.c_double, [i32, i32, f32, C.POINTER(i32), C.POINTER(i32)]),
 }
 

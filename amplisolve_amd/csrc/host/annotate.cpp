@@ -47,6 +47,42 @@ double fisher_two_sided(int a, int b, int c, int d)
     auto lchoose = [](double nn, double kk) { return std::lgamma(nn + 1) - std::lgamma(kk + 1) - std::lgamma(nn - kk + 1); };
     const double ldenom = lchoose(N, n);
     auto pmf = [&](unsigned k) { return std::exp(lchoose(r, k) + lchoose((double)N - r, (double)n - k) - ldenom); };
+    const double cutoff = pmf((unsigned)c) * (1 + 1e-7);
+    if (max_for_k < min_for_k) return 0.0;
+    // The support can be thousands of k wide (r, n of the order of the read depth) and only the pmf values are needed, so
+    // the log-gamma form is evaluated once, at the mode, and the rest follows from the ratio of neighbouring terms
+    //   pmf(k+1) / pmf(k) = (r-k)(n-k) / ((k+1)(N-r-n+k+1))
+    // walked outwards in both directions (each step one multiplication and one division; ~1e-13 relative after a few
+    // thousand steps, six orders inside the 1e-7 tie tolerance and the six digits that are printed).
+    const double Nd = N, rd = r, nd = n;
+    unsigned mode = (unsigned)std::floor((rd + 1) * (nd + 1) / (Nd + 2));
+    mode = std::min(std::max(mode, min_for_k), max_for_k);
+    const double p_mode = pmf(mode);
+    double tmp_p = p_mode <= cutoff ? p_mode : 0.0;
+    double p = p_mode;
+    for (unsigned k = mode; k < max_for_k; ++k) { // upwards: pmf(k+1) from pmf(k)
+        p *= ((rd - k) * (nd - k)) / (((double)k + 1) * (Nd - rd - nd + k + 1));
+        if (p <= cutoff) tmp_p += p;
+        if (p == 0) break;
+    }
+    p = p_mode;
+    for (unsigned k = mode; k > min_for_k; --k) { // downwards: pmf(k-1) from pmf(k)
+        p *= ((double)k * (Nd - rd - nd + k)) / ((rd - k + 1) * (nd - k + 1));
+        if (p <= cutoff) tmp_p += p;
+        if (p == 0) break;
+    }
+    return tmp_p;
+}
+
+// the same sum with every term from the log-gamma form (round 1-3; kept as the check of the recurrence: tests/test_host_logic.py)
+double fisher_two_sided_direct(int a, int b, int c, int d)
+{
+    const unsigned N = (unsigned)(a + b + c + d), r = (unsigned)(a + c), n = (unsigned)(c + d);
+    const unsigned max_for_k = std::min(r, n);
+    const unsigned min_for_k = (unsigned)std::max(0, (int)(r + n - N));
+    auto lchoose = [](double nn, double kk) { return std::lgamma(nn + 1) - std::lgamma(kk + 1) - std::lgamma(nn - kk + 1); };
+    const double ldenom = lchoose(N, n);
+    auto pmf = [&](unsigned k) { return std::exp(lchoose(r, k) + lchoose((double)N - r, (double)n - k) - ldenom); };
     const double cutoff = pmf((unsigned)c);
     double tmp_p = 0.0;
     for (unsigned k = min_for_k; k < max_for_k + 1; ++k) {

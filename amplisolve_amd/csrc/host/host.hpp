@@ -32,12 +32,18 @@ struct Panel {
     std::vector<std::string> ref_base;                // per p, as read (case preserved)
     std::vector<uint8_t> ref_code;                    // 0..3 = A,C,G,T (exact, upper case), 255 otherwise
     std::vector<uint8_t> dup;                         // per p: listed more than once (EE:657-664)
-    // error-table columns, when the panel was loaded from positionSpecificNoise_*.txt (VC:430-576)
-    std::vector<std::string> thr_text[4], germ_text[4];
+    // error-table columns, when the panel was loaded from positionSpecificNoise_*.txt (VC:430-576): the file's text with
+    // every cell NUL-terminated in place, and per unique position the offsets of its 4 threshold + 4 germ-max cells
+    std::string table_text;
+    std::vector<uint32_t> cell_off[8];
+    bool from_table() const { return !cell_off[0].empty() || (!table_text.empty() && pos_coord.empty()); }
+    const char *thr_cell(int nt, int64_t p) const { return table_text.data() + cell_off[nt][(size_t)p]; }      // Thresholds_Hash_Analytic (VC:519-538)
+    const char *germ_cell(int nt, int64_t p) const { return table_text.data() + cell_off[4 + nt][(size_t)p]; } // Germline_Max_Hash (VC:541-560)
 
     int64_t P() const { return (int64_t)pos_coord.size(); }
     int find(const std::string &chrom, int coord) const;
     int add_position(const std::string &chrom, int coord);
+    int add_position_id(int chrom_id_, int coord); // the chromosome is already in `chroms`
     void set_ref(uint32_t p, const std::string &base);
 };
 
@@ -203,6 +209,7 @@ int run_error_estimation(const EeArgs &a);
 int run_variant_calling(const VcArgs &a);
 // ---- annotate.cpp ----
 double fisher_two_sided(int a, int b, int c, int d);                            // VC:3797-3814 (own hypergeometric pmf)
+double fisher_two_sided_direct(int a, int b, int c, int d);                     // the same, every term from log-gamma (check)
 long double score_reference_sequence(int k, int rd, float err);                 // VC:3834-3884, for calls within rounding of a gate
 std::string kmer_down(const Panel &p, const std::string &chrom, int pos);       // VC:3307-3458
 std::string kmer_up(const Panel &p, const std::string &chrom, int pos);         // VC:3461-3613

@@ -159,8 +159,8 @@ extern "C" const char *ampli_host_table_cell(const ampli_host_cohort *h, int64_t
     if (!h || p < 0 || p >= h->panel.P() || which < 0 || which > 8) return nullptr;
     const Panel &pn = h->panel;
     if (which == 0) return (size_t)p < pn.ref_base.size() ? pn.ref_base[(size_t)p].c_str() : nullptr;
-    const std::vector<std::string> &col = which <= 4 ? pn.thr_text[which - 1] : pn.germ_text[which - 5];
-    return (size_t)p < col.size() ? col[(size_t)p].c_str() : nullptr;
+    if (pn.cell_off[which - 1].size() != (size_t)pn.P()) return nullptr; // not loaded from a table
+    return pn.table_text.data() + pn.cell_off[which - 1][(size_t)p];
 }
 
 extern "C" int ampli_host_context(const ampli_host_cohort *h, int64_t p, char sub, char *down, char *up, int32_t cap)
@@ -249,6 +249,7 @@ extern "C" int ampli_host_bam_scan(const char *bam, int32_t threads, int64_t *st
 }
 
 extern "C" double ampli_host_fisher(int a, int b, int c, int d) { return fisher_two_sided(a, b, c, d); }
+extern "C" double ampli_host_fisher_direct(int a, int b, int c, int d) { return fisher_two_sided_direct(a, b, c, d); }
 
 extern "C" double ampli_host_guard_score(int32_t k, int32_t rd, float err, int32_t *ge5, int32_t *lt20)
 {

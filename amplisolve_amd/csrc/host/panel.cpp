@@ -31,11 +31,15 @@ int Panel::add_position(const std::string &chrom, int coord)
     } else {
         cid = c->second;
     }
+    return add_position_id(cid, coord);
+}
+
+int Panel::add_position_id(int cid, int coord)
+{
     const uint64_t key = ((uint64_t)(uint32_t)cid << 32) | (uint32_t)coord;
-    auto it = index.find(key);
-    if (it != index.end()) return (int)it->second;
     const uint32_t p = (uint32_t)pos_coord.size();
-    index.emplace(key, p);
+    auto ins = index.emplace(key, p);
+    if (!ins.second) return (int)ins.first->second;
     pos_chrom.push_back(cid);
     pos_coord.push_back(coord);
     ref_base.emplace_back();

@@ -199,6 +199,37 @@ struct DevAsync {
     }
 };
 
+// work that nothing downstream waits for (by-product files, freeing the ring): runs beside the main thread, joined when the
+// owner leaves its scope; an exception is rethrown by wait()
+struct Background {
+    std::thread th;
+    std::exception_ptr ex;
+    template <class F> void run(F &&f)
+    {
+        wait();
+        th = std::thread([this, f]() mutable {
+            try {
+                f();
+            } catch (...) {
+                ex = std::current_exception();
+            }
+        });
+    }
+    void wait()
+    {
+        if (th.joinable()) th.join();
+        if (ex) {
+            std::exception_ptr e = ex;
+            ex = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    ~Background()
+    {
+        if (th.joinable()) th.join();
+    }
+};
+
 size_t chunk_bytes_setting()
 {
     // about this many bytes of records (in the narrowest layout) per chunk (AMPLISOLVE_CHUNK_MB); three chunks are in flight
@@ -473,12 +504,17 @@ int run_error_estimation(const EeArgs &a)
 
         double t0 = now_s();
         Panel panel;
+        Background interm_files, ring_teardown; // declared after the panel: they are joined before it goes away
         {
             PhaseClock::Scope sc("panel");
             panel_from_bed(a.panel_design, panel);
             if (!a.refbases_file.empty()) panel_load_refbases_file(panel, a.refbases_file);
             else panel_load_fasta(panel, a.reference_genome);
-            if (writer) panel_write_interm_files(panel, interm, seed);
+            // the five by-product files of generateReferenceBases (EE:601-664) are read by nothing downstream
+            if (writer) interm_files.run([&panel, interm, seed] {
+                PhaseClock::Scope sc2("interm_files", false);
+                panel_write_interm_files(panel, interm, seed);
+            });
         }
         std::cout << "\nRunning function generateReferenceBases: Reference bases and amplicon duplicated positions have generated"
                   << "\n\t\t --> Parsed in total " << panel.rows.size() << " amplicons and annotated " << panel.walk.size() << " positions." << std::endl;
@@ -574,9 +610,11 @@ int run_error_estimation(const EeArgs &a)
                 }
                 parse_s += cs.parse_seconds();
                 PhaseClock::add("parser_busy", cs.parse_seconds(), false);
-                const double d0 = now_s();
-                cs.shutdown(); // joins the producer and frees the ring here, where it can be timed
-                PhaseClock::add("stream_teardown", now_s() - d0, true);
+                ChunkStream *done_stream = own.release(); // unpinning + unmapping the ring: beside the download and the table writer
+                ring_teardown.run([done_stream] {
+                    PhaseClock::Scope sc2("stream_teardown", false);
+                    delete done_stream;
+                });
             }
             int32_t kflags = 0;
             dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
@@ -634,6 +672,11 @@ int run_error_estimation(const EeArgs &a)
         if (writer) {
             PhaseClock::Scope sc("write_table");
             write_error_table(panel, rate.data(), code.data(), germ.data(), gp.data(), out);
+        }
+        {
+            PhaseClock::Scope sc("join_background");
+            interm_files.wait();
+            ring_teardown.wait();
         }
         if (sh) hook(sh->barrier(sh->user), "barrier");
         double t4 = now_s();
@@ -712,6 +755,7 @@ int run_variant_calling(const VcArgs &a)
         const double t0 = now_s();
         Panel panel;
         std::vector<float> thr;
+        Background ring_teardown; // after the panel: joined before it goes away
         {
             PhaseClock::Scope sc("read_table");
             panel_from_error_table(a.error_file, writer ? interm + "/dummyVCF_1.vcf" : std::string(), panel, thr); // VC:320
@@ -745,7 +789,8 @@ int run_variant_calling(const VcArgs &a)
             // tumour files are independent given the error table: they stream through in chunks (parsing of the next
             // chunks overlaps upload + kernels of this one); only the emitted calls come back.  The parsers start before
             // the context is waited for.
-            ChunkStream cs(panel, files, threads, true, chunk_bytes_setting(), 4);
+            std::unique_ptr<ChunkStream> own(new ChunkStream(panel, files, threads, true, chunk_bytes_setting(), 4));
+            ChunkStream &cs = *own;
             Dev &dev = dev_async.get();
             float *d_thr = dev.upload(thr.data(), thr.size());
             uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
@@ -825,9 +870,11 @@ int run_variant_calling(const VcArgs &a)
             }
             parse_s = cs.parse_seconds();
             PhaseClock::add("parser_busy", parse_s, false);
-            const double d0 = now_s();
-            cs.shutdown();
-            PhaseClock::add("stream_teardown", now_s() - d0, true);
+            ChunkStream *done_stream = own.release(); // unpinning + unmapping the ring: beside the annotation and the writers
+            ring_teardown.run([done_stream] {
+                PhaseClock::Scope sc2("stream_teardown", false);
+                delete done_stream;
+            });
         }
         const double t2 = now_s();
         // Calls within rounding of a gate.  The device forms Q in fp64 with ROCm's exp / log, the reference with glibc and an
@@ -836,6 +883,7 @@ int run_variant_calling(const VcArgs &a)
         // re-evaluated here with the reference's own operation sequence before it is gated, flagged or printed.
         int64_t n_guarded = 0, n_dropped = 0;
         {
+            PhaseClock::Scope sc("guard_and_sort");
             std::vector<CallRow> kept;
             kept.reserve(rows.size());
             for (CallRow &c : rows) {
@@ -851,13 +899,13 @@ int run_variant_calling(const VcArgs &a)
                 kept.push_back(c);
             }
             rows.swap(kept);
+            // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
+            std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
+                if (x.sample != y.sample) return x.sample < y.sample;
+                if (x.line != y.line) return x.line < y.line;
+                return x.alt < y.alt;
+            });
         }
-        // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
-        std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
-            if (x.sample != y.sample) return x.sample < y.sample;
-            if (x.line != y.line) return x.line < y.line;
-            return x.alt < y.alt;
-        });
 
         const std::string summary = a.output_dir + "/Summary_Variant_Info.txt"; // VC:342
         // multi-process run: every shard writes its rows to a part file; shard 0 concatenates them in shard order, which is
@@ -869,6 +917,76 @@ int run_variant_calling(const VcArgs &a)
         if (before > 0) output << std::setprecision(4);
         if (writer)
         output << "Filename\tChrom\tPosition\tSubtitution\tRD\tRD_fw\tRD_bw\tAF\tReads_fw\tReads_bw\tAF_fw\tAF_bw\tAmpliconEdge_StrandBias\tFisherPvalue\tQscore_fw\tQscore_bw\tReadTier\tGermlineInfo\tMaxGermlineAF\t10merDownstream\t10merUpstream\tHomopolymerFlag" << std::endl; // VC:669
+        // Annotation of the emitted calls (Fisher, context, flags: VC:902-1034) and the two text rows of each are independent
+        // of every other call: formatted by a few threads, written in order.  VC:1066 sets std::setprecision(4) mid-row and it
+        // sticks, so only the first row EVER written (this shard's row 0 when no shard before it emitted) prints its AF columns
+        // with the stream's default 6 digits; every VCF row comes from a stream that is still at its default (VC:679).
+        std::vector<std::string> sum_line(rows.size()), vcf_line(rows.size());
+        {
+            PhaseClock::Scope sc("annotate");
+            int nt_ann = (int)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, rows.size() / 64));
+            if (const char *e = getenv("AMPLISOLVE_THREADS")) nt_ann = std::max(1, std::min(nt_ann, atoi(e)));
+            auto annotate = [&](int tid) {
+                std::ostringstream output, vcf;
+                const size_t i0 = rows.size() * (size_t)tid / (size_t)nt_ann, i1 = rows.size() * (size_t)(tid + 1) / (size_t)nt_ann;
+                for (size_t i = i0; i < i1; ++i) {
+                    const CallRow &c = rows[i];
+                    output.str(std::string());
+                    vcf.str(std::string());
+                    output << std::setprecision((i == 0 && before == 0) ? 6 : 4);
+                    const std::string &sample_name = files[(size_t)c.sample].second;
+                    const int64_t p = c.p;
+                    const std::string &chrom = panel.chroms[panel.pos_chrom[p]];
+                    const int pos = panel.pos_coord[p];
+                    const int FW = c.fw, BW = c.bw, RD = c.rd; // VC:760-761 and the RD column
+                    const int alt_fw = c.k_fw, alt_bw = c.k_bw;
+                    const char refc = "ACGT"[panel.ref_code[p]], altc = "ACGT"[c.alt];
+                    const std::string Flag_Dup = panel.dup[p] ? "YES" : "NO";
+                    const double pf = fisher_two_sided(RD - BW, BW, alt_fw, alt_bw);      // VC:902
+                    const std::string Flag_Fisher = pf <= p_value ? "YES" : "NO";         // VC:903-910
+                    const std::string Flag_Tier = (alt_fw < 5 || alt_bw < 5) ? "LowQual" : "HighQual"; // VC:912-919
+                    const std::string GermlineFlag = "-";                                 // VC:927-935 (map holds a dummy entry only)
+                    const std::string MaxGermlineFlag = panel.germ_cell(c.alt, p);        // VC:943-954
+                    const std::string down = kmer_down(panel, chrom, pos), up = kmer_up(panel, chrom, pos);
+                    const double Q = (c.q_fw + c.q_bw) / 2.000;                           // VC:968
+                    const std::string cat = Flag_Dup + "_" + Flag_Fisher;
+                    const double max_germ = std::atof(MaxGermlineFlag.c_str());           // VC:972
+                    const int homo = homopolymer_test(down, up, altc);
+                    // VC:993-1034: flags go through an unordered_map and come out in ITS order
+                    std::unordered_map<std::string, std::string> Flag_Hash;
+                    int OK = 0;
+                    auto put = [&](const char *f) { OK = 1; Flag_Hash.insert(std::make_pair<std::string, std::string>(f, f)); };
+                    if (cat == "YES_NO") put("AmpliconEdge");
+                    if (cat == "YES_YES") put("AmpliconEdge;StrandBias");
+                    if (cat == "NO_YES") put("StrandBias");
+                    if (c.af < max_germ && cat == "NO_NO" && Flag_Tier != "HighQual") put("PositionWithHighNoise");
+                    if (homo == 1) put("HomoPolymerRegion");
+                    if (c.q_fw < 20 || c.q_bw < 20) put("LowQ");
+                    if (Flag_Tier != "HighQual") put("LowSupportingReads");
+                    std::string filter = "PASS";
+                    if (OK) {
+                        filter.clear();
+                        for (auto it = Flag_Hash.begin(); it != Flag_Hash.end(); ++it) filter += (filter.empty() ? "" : ";") + it->first;
+                    }
+                    // the C->G block writes "-" instead of "." as ID when the call is not a PASS (VC:1856)
+                    const char *id = (!OK || !(refc == 'C' && altc == 'G')) ? "." : "-";
+                    vcf << chrom << "\t" << pos << "\t" << id << "\t" << refc << "\t" << altc << "\t" << Q << "\t" << filter << "\t" << c.af << ";" << RD
+                        << ";" << alt_fw + alt_bw << "\n"; // VC:1040 / 1062
+                    // VC:1066 -- std::setprecision(4) is set mid-row and sticks for every later row of the file
+                    output << sample_name << "\t" << chrom << "\t" << pos << "\t" << refc << "->" << altc << "\t" << RD << "\t" << FW << "\t" << BW << "\t"
+                           << c.af << "\t" << alt_fw << "\t" << alt_bw << "\t" << c.af_fw << "\t" << c.af_bw << "\t" << Flag_Dup << "_" << Flag_Fisher
+                           << "\t" << pf << "\t" << std::setprecision(4) << c.q_fw << "\t" << std::setprecision(4) << c.q_bw << "\t" << Flag_Tier << "\t"
+                           << GermlineFlag << "\t" << MaxGermlineFlag << "\t" << down << "\t" << up << "\t" << homo << "\n";
+                    sum_line[i] = output.str();
+                    vcf_line[i] = vcf.str();
+                }
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt_ann; ++t) th.emplace_back(annotate, t);
+            annotate(0);
+            for (auto &x : th) x.join();
+        }
+        PhaseClock::Scope sc_w("write_calls");
         size_t ri = 0;
         for (int t = 0; t < T; ++t) {
             const std::string &sample_name = files[(size_t)t].second;
@@ -882,49 +1000,8 @@ int run_variant_calling(const VcArgs &a)
                 << std::endl; // VC:688
             if ((t + 1) % 50 == 0) std::cout << "\tParsed successfully " << t + 1 << "/" << T << "  samples" << std::endl;
             for (; ri < rows.size() && rows[ri].sample == t; ++ri) {
-                const CallRow &c = rows[ri];
-                const int64_t p = c.p;
-                const std::string &chrom = panel.chroms[panel.pos_chrom[p]];
-                const int pos = panel.pos_coord[p];
-                const int FW = c.fw, BW = c.bw, RD = c.rd; // VC:760-761 and the RD column
-                const int alt_fw = c.k_fw, alt_bw = c.k_bw;
-                const char refc = "ACGT"[panel.ref_code[p]], altc = "ACGT"[c.alt];
-                const std::string Flag_Dup = panel.dup[p] ? "YES" : "NO";
-                const double pf = fisher_two_sided(RD - BW, BW, alt_fw, alt_bw);      // VC:902
-                const std::string Flag_Fisher = pf <= p_value ? "YES" : "NO";         // VC:903-910
-                const std::string Flag_Tier = (alt_fw < 5 || alt_bw < 5) ? "LowQual" : "HighQual"; // VC:912-919
-                const std::string GermlineFlag = "-";                                 // VC:927-935 (map holds a dummy entry only)
-                const std::string MaxGermlineFlag = panel.germ_text[c.alt][p];        // VC:943-954
-                const std::string down = kmer_down(panel, chrom, pos), up = kmer_up(panel, chrom, pos);
-                const double Q = (c.q_fw + c.q_bw) / 2.000;                           // VC:968
-                const std::string cat = Flag_Dup + "_" + Flag_Fisher;
-                const double max_germ = std::atof(MaxGermlineFlag.c_str());           // VC:972
-                const int homo = homopolymer_test(down, up, altc);
-                // VC:993-1034: flags go through an unordered_map and come out in ITS order
-                std::unordered_map<std::string, std::string> Flag_Hash;
-                int OK = 0;
-                auto put = [&](const char *f) { OK = 1; Flag_Hash.insert(std::make_pair<std::string, std::string>(f, f)); };
-                if (cat == "YES_NO") put("AmpliconEdge");
-                if (cat == "YES_YES") put("AmpliconEdge;StrandBias");
-                if (cat == "NO_YES") put("StrandBias");
-                if (c.af < max_germ && cat == "NO_NO" && Flag_Tier != "HighQual") put("PositionWithHighNoise");
-                if (homo == 1) put("HomoPolymerRegion");
-                if (c.q_fw < 20 || c.q_bw < 20) put("LowQ");
-                if (Flag_Tier != "HighQual") put("LowSupportingReads");
-                std::string filter = "PASS";
-                if (OK) {
-                    filter.clear();
-                    for (auto it = Flag_Hash.begin(); it != Flag_Hash.end(); ++it) filter += (filter.empty() ? "" : ";") + it->first;
-                }
-                // the C->G block writes "-" instead of "." as ID when the call is not a PASS (VC:1856)
-                const char *id = (!OK || !(refc == 'C' && altc == 'G')) ? "." : "-";
-                vcf << chrom << "\t" << pos << "\t" << id << "\t" << refc << "\t" << altc << "\t" << Q << "\t" << filter << "\t" << c.af << ";" << RD
-                    << ";" << alt_fw + alt_bw << std::endl; // VC:1040 / 1062
-                // VC:1066 -- std::setprecision(4) is set mid-row and sticks for every later row of the file
-                output << sample_name << "\t" << chrom << "\t" << pos << "\t" << refc << "->" << altc << "\t" << RD << "\t" << FW << "\t" << BW << "\t"
-                       << c.af << "\t" << alt_fw << "\t" << alt_bw << "\t" << c.af_fw << "\t" << c.af_bw << "\t" << Flag_Dup << "_" << Flag_Fisher
-                       << "\t" << pf << "\t" << std::setprecision(4) << c.q_fw << "\t" << std::setprecision(4) << c.q_bw << "\t" << Flag_Tier << "\t"
-                       << GermlineFlag << "\t" << MaxGermlineFlag << "\t" << down << "\t" << up << "\t" << homo << std::endl;
+                vcf << vcf_line[ri];
+                output << sum_line[ri];
             }
         }
         output.close();
@@ -947,7 +1024,7 @@ int run_variant_calling(const VcArgs &a)
                 if (all.fail()) throw Error{AMPLI_E_INVALID, "could not write " + summary};
             }
         }
-        PhaseClock::add("annotate_and_write", now_s() - t2, true);
+        ring_teardown.wait();
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING table " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done << " parse_busy "
                       << parse_s << " record_MB " << rec_bytes_up / 1e6 << " calls " << rows.size() << " guarded " << n_guarded << " dropped_by_guard " << n_dropped << "\nTIMING annotate+write " << now_s() - t2 << std::endl;

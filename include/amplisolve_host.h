@@ -159,6 +159,8 @@ double ampli_host_guard_score(int32_t k, int32_t rd, float err, int32_t *ge5, in
 
 /* two-sided Fisher exact test of the post-call annotation (VC:3797-3814; own pmf, parity unpinned vs Boost) */
 double ampli_host_fisher(int a, int b, int c, int d);
+/* the same sum with every term taken from the log-gamma form (slow; the check of the recurrence ampli_host_fisher walks) */
+double ampli_host_fisher_direct(int a, int b, int c, int d);
 
 #ifdef __cplusplus
 }

@@ -145,6 +145,50 @@ def test_error_table_io_does_not_depend_on_the_thread_count(tmp_path, monkeypatc
     assert np.array_equal(thrs[0].view(np.int32), thrs[1].view(np.int32))
 
 
+def test_error_table_writer_prints_like_printf(tmp_path):
+    """The writer forms "%f" by exact integer arithmetic and "%g" through the C library (round 4, csrc/host/table.cpp put_f6):
+    every cell must be what the reference's sprintf("%f_%f") (EE:1704) / `ostream << double` (EE:2807-2849) print -- checked
+    against the C library's own formatting of the same floats: bit patterns drawn over the whole range (denormals, halves
+    that round to even, negative values, values beyond 2^20 that take the fallback) and the error-rate range itself."""
+    import ctypes as C
+
+    libc = C.CDLL(None)
+    libc.snprintf.restype = C.c_int
+    bed = tmp_path / "p.bed"
+    bed.write_text("chr1\t1\t30000\n")
+    refb = tmp_path / "ref.txt"
+    refb.write_text("".join(f"chr1\t{p}\tN\n" for p in range(1, 30001)))  # N: no cell is the "-2_-2" of a reference base
+    co = HostCohort(str(bed), refbases_file=str(refb))
+    P = co.P
+    rng = np.random.default_rng(12)
+    bits = rng.integers(0, 2**32, (2, 4, P), dtype=np.uint64).astype(np.uint32)
+    rate = bits.view(np.float32).copy()
+    rate[~np.isfinite(rate)] = np.float32(0.25)
+    rate[:, :, : P // 3] = (rng.random((2, 4, P // 3)) * 0.06).astype(np.float32)              # the range rates live in
+    k = rng.integers(0, 4000000, (2, 4, P // 3))
+    rate[:, :, P // 3: 2 * (P // 3)] = ((2 * k + 1) / 2e6).astype(np.float32)                   # next to the ...5 ties of the 7th decimal
+    rate[0, 0, :8] = np.array([0.0, -0.0, 1e-7, 5e-7, 1.5e-6, 2.5e-6, 1048575.9, 1048576.0], np.float32)
+    gval = bits[0].view(np.float32).copy()
+    gval[~np.isfinite(gval)] = np.float32(0.5)
+    gval[:, : P // 2] = (rng.random((4, P // 2)) * 0.05).astype(np.float32)
+    gval[0, :4] = np.array([0.0, -0.0, -888.0, 0.00170648], np.float32)
+    out = tmp_path / "t.txt"
+    co.write_error_table(rate, np.zeros((4, P), np.uint8), gval, np.ones((4, P), np.uint8), str(out))
+    rows = out.read_text().splitlines()[1:]
+    assert len(rows) == P
+    buf = C.create_string_buffer(128)
+
+    def fmt(f, v):
+        libc.snprintf(buf, 128, f, C.c_double(float(v)))
+        return buf.value.decode()
+
+    for p in range(0, P, 1):
+        cells = rows[p].split("\t")
+        for nt in range(4):
+            assert cells[4 + nt] == fmt(b"%f", rate[0, nt, p]) + "_" + fmt(b"%f", rate[1, nt, p]), (p, nt, rate[:, nt, p])
+            assert cells[8 + nt] == fmt(b"%g", gval[nt, p]), (p, nt, gval[nt, p])
+
+
 def test_fisher_matches_scipy():
     scipy = pytest.importorskip("scipy.stats")
     H = host_lib()
@@ -157,6 +201,26 @@ def test_fisher_matches_scipy():
         want = scipy.fisher_exact([[a, c], [b, d]])[1]
         assert got == pytest.approx(want, rel=1e-6, abs=1e-12)
     assert H.ampli_host_fisher(461, 536, 196, 223) == pytest.approx(0.861148, abs=5e-7)  # SURVEY App. D, first Toy_data call
+
+
+def test_fisher_recurrence_equals_the_term_by_term_sum():
+    """ampli_host_fisher walks the pmf outwards from the mode by the ratio of neighbouring terms (round 4: the term-by-term
+    log-gamma sum cost ~60-100 us per call at config-3 depths, the walk 3 us); it must print like the direct sum: equal to
+    2e-9 relative -- the direct sum's own error at N ~ 2e5 is ~1e-10 per term (lgamma(N) ~ 1e6 carries an absolute error of
+    ~2e-10), the walk's is smaller -- far inside the six digits of the Summary; small tables, deep ones, empty margins and
+    the one-sided extremes."""
+    H = host_lib()
+    rng = np.random.default_rng(8)
+    cases = [(0, 0, 0, 0), (5, 0, 0, 5), (0, 7, 3, 0), (1, 1, 1, 1), (3000, 2500, 2900, 10), (10, 12, 4000, 3900), (461, 536, 196, 223)]
+    for _ in range(1500):
+        hi = int(rng.choice([5, 60, 3000, 60000]))
+        cases.append(tuple(int(x) for x in rng.integers(0, hi + 1, 4)))
+    for _ in range(500):  # the shape the caller sees: depths and a smaller alt count per strand
+        a, b = (int(x) for x in rng.integers(100, 30000, 2))
+        cases.append((a, b, int(rng.integers(0, a + 1) * rng.random() ** 3), int(rng.integers(0, b + 1) * rng.random() ** 3)))
+    for a, b, c, d in cases:
+        got, want = H.ampli_host_fisher(a, b, c, d), H.ampli_host_fisher_direct(a, b, c, d)
+        assert got == pytest.approx(want, rel=2e-9, abs=1e-300), (a, b, c, d, got, want)
 
 
 def test_multi_front_end_token_parsing_and_usage(capsys):
