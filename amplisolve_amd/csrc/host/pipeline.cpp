@@ -103,8 +103,32 @@ struct Dev {
         }
         int dev = 0;
         if (const char *e = getenv("AMPLISOLVE_DEVICE")) dev = atoi(e);
-        PhaseClock::Scope sc("context_create", !side); // hipSetDevice + properties + the first hipMalloc / hipMemset
-        check(api->ctx_create(dev, nullptr, &ctx), "ampli_ctx_create");
+        {
+            PhaseClock::Scope sc("context_create", !side); // hipSetDevice + properties + the first hipMalloc / hipMemset
+            check(api->ctx_create(dev, nullptr, &ctx), "ampli_ctx_create");
+        }
+        if (side) warm_copies();
+    }
+    // The first copy in each direction sets up the runtime's copy machinery (staging buffers, the DMA queues: ~8 ms each,
+    // tools/micro/init_probe.cpp).  On the side thread that cost hides behind the parsers; paid later it sits on the main
+    // thread's path, in front of the first upload and of the table download.
+    void warm_copies()
+    {
+        PhaseClock::Scope sc("warm_copies", false);
+        const size_t n = 1 << 16;
+        void *d = nullptr, *pin = nullptr;
+        if (api->dev_alloc(ctx, n, &d) != AMPLI_OK) return;
+        std::vector<char> pageable(n, 1);
+        if (api->pinned_alloc(n, &pin) == AMPLI_OK) { // the uploads come from pinned (registered) memory
+            memset(pin, 1, n);
+            (void)api->copy_h2d(ctx, d, pin, n);
+            (void)api->copy_d2h(ctx, pin, d, n);
+        }
+        (void)api->copy_h2d(ctx, d, pageable.data(), n); // small host arrays and the results travel pageable
+        (void)api->copy_d2h(ctx, pageable.data(), d, n);
+        (void)api->sync(ctx);
+        if (pin) (void)api->pinned_free(pin);
+        (void)api->dev_free(ctx, d);
     }
     template <class T> T *alloc(size_t n)
     {

@@ -29,6 +29,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_PEAK_TFLOPS = 78.6  # vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flops (FMA) x 2.4 GHz = half of the guide's 157.3 TF FP32 vector figure
+# (MI355X_MICROARCH.md counts packed FP32, two per lane); v_fma_f64 measured at full issue rate, 4 cycles per wave instruction (tools/micro/op_rates.hip)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 SEED = 0xA3F15017 + 2   # seed base + config index
 
@@ -37,6 +39,9 @@ CONFIGS = {
     "c3": dict(P=100_000, S=256, T=96, depth=2000, strong=False, name="synthetic 100k positions x 256 normals x 96 tumours (ctDNA-scale)"),
     # BASELINE configs[3]: the WHOLE job is 1024 normals + 1024 tumours; N ranks take 1024/N of each (strong scaling)
     "c4": dict(P=100_000, S=1024, T=1024, depth=2000, strong=True, name="synthetic 100k positions x 1024 normals x 1024 tumours, split over the GPUs"),
+    # BASELINE configs[4]: 1 M positions x 256 normals at 50 000x (T is not given there: 64 = 8 per GPU at N = 8); the
+    # depth does not fit uint16, so --records auto holds it in 24-byte records; the fixed job is split over the GPUs (strong)
+    "c5": dict(P=1_000_000, S=256, T=64, depth=50_000, strong=True, name="synthetic 1M positions x 256 normals x 64 tumours, depth 50000x (VAF 1% stress), split over the GPUs"),
 }
 
 
@@ -118,6 +123,10 @@ def _run_timed(cmd, cwd, env=None):
         out, err = fo.read(), fe.read()
     timing = {}
     for ln in err.splitlines():
+        if ln.startswith("TIMING2 "):  # the phase clock: name seconds critical|overlapped|total
+            w = ln.split()
+            timing.setdefault("phases", {})[w[1] + ("*" if w[3] == "overlapped" else "")] = round(float(w[2]), 4)
+            continue
         if ln.startswith("TIMING"):
             w = ln.split()
             timing[w[1]] = float(w[2])
@@ -172,14 +181,21 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                                  "host_peak_rss_MB": ee_rss,
                                  "phases_s": {"panel": ee_t.get("panel"), "stream(parse+upload+reduce)": ee_t.get("stream"), "parser_busy": ee_t.get("stream.parse_busy"),
                                               "waiting_for_gpu": ee_t.get("stream.device_wait"), "table_write": ee_t.get("write")},
-                                 "chunks": int(ee_t.get("stream.chunks", 0))},
+                                 "chunks": int(ee_t.get("stream.chunks", 0)),
+                                 # where the wall time goes: the phase clock of the executable (csrc/host/pipeline.cpp PhaseClock).
+                                 # Entries without * lie on the main thread's path and add up to wall_in_main; entries with * ran
+                                 # on other threads beside it (runtime start-up, parsers, by-product files, ring teardown)
+                                 "breakdown_s": ee_t.get("phases"),
+                                 "outside_main_s": round(ee_wall - ee_t.get("phases", {}).get("wall_in_main", ee_wall), 4)},
             "variant_calling": {"wall_s": vc_wall, "records": t_rec, "records_per_s": t_rec / vc_wall, "calls": int(vc_t.get("stream.calls", 0)),
                                 "host_peak_rss_MB": vc_rss,
                                 "phases_s": {"table_read": vc_t.get("table"), "stream(parse+upload+call)": vc_t.get("stream"), "parser_busy": vc_t.get("stream.parse_busy"),
-                                             "annotate+write": vc_t.get("annotate+write")}},
+                                             "annotate+write": vc_t.get("annotate+write")},
+                                "breakdown_s": vc_t.get("phases"),
+                                "outside_main_s": round(vc_wall - vc_t.get("phases", {}).get("wall_in_main", vc_wall), 4)},
             "records_per_s": (n_rec + t_rec) / (ee_wall + vc_wall),
-            "note": "wall clock of the two executables incl. process start and HIP runtime start-up (~0.15 s each); the host packer uploads the "
-                    "narrowest record layout the counts fit (bytes_per_record_uploaded)",
+            "note": "wall clock of the two executables incl. process start and HIP runtime start-up (0.05-0.25 s each: breakdown_s.runtime_init*; "
+                    "the parsers run beside it); the host packer uploads the narrowest record layout the counts fit (bytes_per_record_uploaded)",
         }
         # the reference's error estimation on the same files (a subset directory of symlinks when the cohort is large)
         ref_dir = "N"
@@ -190,9 +206,14 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                 os.symlink(os.path.join("..", "N", f), os.path.join(d, ref_dir, f))
         ref = reference_ee_run(d, ref_dir, "ref")
         if ref:
-            same = None
-            if ref_dir == "N":  # same files, same directory literal -> same visit order: the tables must be byte-identical
-                same = open(ref["table"], "rb").read() == open(table, "rb").read()
+            # same files, same directory literal -> same visit order: the tables must be byte-identical.  For a subset of the
+            # cohort our executable runs once more, on that subset directory, so that there is a table to compare with
+            ours = table
+            if ref_dir != "N":
+                rc, _, _, out, err, _ = _run_timed([os.path.join(BIN, "AmpliSolveErrorEstimation"), "panel_design=panel.bed", "reference_genome=unused.fa",
+                                                    f"germline_dir={ref_dir}", "C_value=0.002", "coverage_cutoff=100", "default_error=0.01", "output_dir=ee_sub"], d, env)
+                ours = os.path.join(d, "ee_sub", "positionSpecificNoise_0.0020.txt") if rc == 0 else None
+            same = (open(ref["table"], "rb").read() == open(ours, "rb").read()) if ours and os.path.exists(ours) else None
             res["reference_error_estimation"] = {
                 "records": ref["records"], "seconds": ref["seconds"], "records_per_s": ref["records_per_s"], "cores": 1, "phases_s": ref["phases"],
                 "files": ref_files if ref_dir != "N" else S, "table_identical_to_ours": same,
@@ -737,7 +758,22 @@ def main():
 
     t_local_ms = None
     coll_ms, coll_bytes, strong_base = None, None, None
+    single_batch_ms = None
     if multi:
+        # ONE batch with nothing else in flight: reduce -> exchange -> finalize of the slice -> all-gather -> poisson_call, host
+        # clock around it, the slowest rank's figure.  What a single cohort through the command lines sees (their pipeline has
+        # no other batch to hide the collectives behind); ms_per_step above is the pipelined throughput.
+        lat = []
+        for _ in range(5):
+            fence()
+            t1 = time.perf_counter()
+            run_steps(1, False)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        tl = torch.tensor([sorted(lat)[len(lat) // 2]], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        single_batch_ms = float(tl.item()) * 1e3
+        materialise()
         if fins[0] is None:
             fins[0] = ctx.error_estimate(normals, P, 0.002, 100)
         t_local_ms, _ = timed_passes(local_step, max(10, args.steps))
@@ -877,15 +913,13 @@ def main():
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = f"error_reduce_kernel<true, 1, {lay}>", t_red, red_bytes
         else:
-            dom, dom_ms, dom_bytes = f"poisson_stream_kernel<{lay}>+poisson_drain_kernel", t_call, call_bytes
+            dom, dom_ms, dom_bytes = f"poisson_stream_kernel<{lay}, false>+poisson_drain_kernel", t_call, call_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel from the PMC counters: collected with rocprofv3 --pmc in separate passes of
         # this same command (tools/collect_profiles.sh) and corrected as MI355X_MICROARCH.md prescribes; committed
         # under profiles/.  null when the workload is not the profiled one.
         traffic, traffic_src = None, None
-        pj = os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")
-        if not os.path.exists(pj):
-            pj = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+        pj = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("r04", "r03", "r02")) if os.path.exists(p)), "")
         if args.config == "c3" and not multi and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
@@ -898,7 +932,7 @@ def main():
                 traffic = None
         # the other half of the step gets its own roofline entry (same definitions): algorithmic bytes, HIP-event time, PMC traffic
         if t_red >= t_call:
-            oth, oth_ms, oth_bytes = f"poisson_stream_kernel<{lay}>+poisson_drain_kernel", t_call, call_bytes
+            oth, oth_ms, oth_bytes = f"poisson_stream_kernel<{lay}, false>+poisson_drain_kernel", t_call, call_bytes
         else:
             oth, oth_ms, oth_bytes = f"error_reduce_kernel<true, 1, {lay}>", t_red, red_bytes
         oth_traffic = None
@@ -946,6 +980,24 @@ def main():
             "calls_per_step": n_found,
             "borderline_per_step": n_borderline,
         }
+        # The all-scores mode (every record's six Poisson scores, as the reference evaluates them; outside the timed region) is
+        # bound by FP64 vector issue, not by HBM: its own roofline, from the FP64 instruction counters of profiles/ (same
+        # kernel source only).  achieved counts every lane of an issued FP64 wave instruction (an upper bound of the useful
+        # flops: lanes that are masked off in the divergent series / continued-fraction loops are counted too), so
+        # issue_slot_frac -- FP64 wave instructions x 4 cycles / (SIMDs x clock x time) -- is the figure to read.
+        try:
+            fk = next((v for k, v in pm["kernels"].items() if "poisson_call_kernel<0" in k and f", {lay}>" in k and "fp64_wave_instructions" in v), None) if traffic_src else None
+        except Exception:  # noqa: BLE001
+            fk = None
+        out["roofline_fp64"] = {"bound": "fp64 vector issue", "kernel": f"poisson_call_kernel<0, {lay}> (all six scores of every record)", "avg_ms": t_call_full,
+                                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "achieved": (fk["fp64_flops_if_all_lanes_active"] / (t_call_full * 1e-3) / 1e12) if fk else None,
+                                "frac": (fk["fp64_flops_if_all_lanes_active"] / (t_call_full * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if fk else None,
+                                "fp64_wave_instructions_per_launch": fk["fp64_wave_instructions"] if fk else None,
+                                "issue_slot_frac": (fk["fp64_wave_instructions"] * 4 / (1024 * 2.4e9 * t_call_full * 1e-3)) if fk else None,
+                                "hbm_frac_of_the_same_launch": call_bytes / (t_call_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "source": "SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 of profiles/*/pmc_summary.json (offline, same kernel source)" if fk else
+                                          "no FP64 counters for this kernel source under profiles/ (run tools/collect_profiles.sh)"}
         if others:
             out["other_record_layouts"] = others
         if sustained:
@@ -957,7 +1009,11 @@ def main():
                                     "local_step_ms": t_local_ms, "exposed_ms_per_step": max(0.0, ms_per_step - t_local_ms),
                                     "bytes_received_per_rank_and_step": coll_bytes,
                                     "collective_ms_per_round": coll_ms, "batches_per_round": (G if sliced else 1),
-                                    "note": "local_step = reduce + finalize of the rank's own table + poisson_call with no exchange (rank 0, after the "
+                                    "single_batch_latency_ms": single_batch_ms,
+                                    "single_batch_value": (P * S_total + P * T_total) / (single_batch_ms * 1e-3) if single_batch_ms else None,
+                                    "unverified_on_more_than_one_gpu": "efficiency / strong_base / exposed_ms have only been exercised with one rank over RCCL or gloo ranks sharing a GPU until a multi-GPU SCALE run exists",
+                                    "note": "single_batch_latency_ms = one batch with nothing else in flight (median of 5, slowest rank, host clock): the "
+                                            "unpipelined latency beside the pipelined ms_per_step; local_step = reduce + finalize of the rank's own table + poisson_call with no exchange (rank 0, after the "
                                             "timed region); exposed = ms_per_step - local_step; collective_ms_per_round: each collective alone, 10 rounds "
                                             "back to back after the timed region (one round serves batches_per_round batches); world_size and backend as "
                                             "torch.distributed reports them (nccl = RCCL)"}

@@ -3,7 +3,7 @@
 # the CPU baseline and end-to-end legs are switched off).  Outputs under gpurun_out/prof_<round>/ (ROUND, default r03) (merged back by gpurun);
 # tools/make_profile_summary.py turns them into the files committed under profiles/<round>/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof_${ROUND:-r03}
+OUT=$R/gpurun_out/prof_${ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0"
@@ -11,5 +11,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT/pmc_f64 -- $CMD > $OUT/pmc_f64.log 2>&1 || exit 1
 cd $R && timeout -k 10 600 python bench.py > $OUT/bench_default.log 2>&1
 tail -1 $OUT/bench_default.log | cut -c1-400

@@ -2,7 +2,7 @@
 """Turn gpurun_out/prof_final/ (tools/collect_profiles.sh) into the committed summaries under profiles/<round>/."""
 import collections, csv, glob, json, os, shutil, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
@@ -15,7 +15,7 @@ def newest(pattern):
 for f in newest(f"{src}/trace/*/*kernel_stats.csv"):
     shutil.copy(f, f"{dst}/bench_c3_kernel_stats.csv")
 pm = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
     for f in newest(f"{src}/{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             pm[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -31,6 +31,11 @@ for k, d in pm.items():
         row["hbm_read_bytes_corrected"] = 2 * m["FETCH_SIZE"] * 1024
         row["hbm_write_bytes"] = m.get("WRITE_SIZE", 0.0) * 1024
         row["hbm_bytes_per_launch"] = row["hbm_read_bytes_corrected"] + row["hbm_write_bytes"]
+    if "SQ_INSTS_VALU_FMA_F64" in m:
+        # wave-level FP64 vector instructions of one launch; a wave instruction is 64 lane operations (an FMA two flops each)
+        f64 = {c: m.get(f"SQ_INSTS_VALU_{c}_F64", 0.0) for c in ("ADD", "MUL", "FMA", "TRANS")}
+        row["fp64_wave_instructions"] = sum(f64.values())
+        row["fp64_flops_if_all_lanes_active"] = 64 * (f64["ADD"] + f64["MUL"] + 2 * f64["FMA"] + f64["TRANS"])
     out[k] = row
 import hashlib
 h = hashlib.sha256()
