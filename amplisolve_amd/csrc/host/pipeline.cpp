@@ -575,8 +575,11 @@ int run_error_estimation(const EeArgs &a)
         // the parsers start NOW, into plain memory, while the runtime is still coming up on the side thread
         std::unique_ptr<ChunkStream> first_stream;
         if (S > 0) first_stream.reset(new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), 4));
-        Dev &dev = dev_async.get();
+        // the host copies of the table are made (their pages touched) while the runtime is still starting, not in front of the download
         const int64_t P = panel.P();
+        std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
+        std::vector<uint8_t> code((size_t)P * 4), gp((size_t)P * 4);
+        Dev &dev = dev_async.get();
         float *d_rate = dev.alloc<float>((size_t)P * 8), *d_germ = dev.alloc<float>((size_t)P * 4);
         uint8_t *d_code = dev.alloc<uint8_t>((size_t)P * 4), *d_gp = dev.alloc<uint8_t>((size_t)P * 4);
         int32_t *d_flags = dev.alloc<int32_t>(1);
@@ -641,7 +644,10 @@ int run_error_estimation(const EeArgs &a)
                 });
             }
             int32_t kflags = 0;
-            dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+            {
+                PhaseClock::Scope sc("device_wait");
+                dev.check(dev.api->ctx_flags(dev.ctx, &kflags, 1), "ampli_ctx_flags");
+            }
             if (sh) hook(sh->or_flags(sh->user, &kflags), "or_flags");
             if (!(kflags & AMPLI_FLAG_RERUN_GENERAL) || attempt == 1) break;
             dev.check(dev.api->set_tuning(dev.ctx, 0, 1, 0), "ampli_set_tuning"); // a depth beyond the fast kernel (on some shard): all stream again
@@ -678,8 +684,6 @@ int run_error_estimation(const EeArgs &a)
         } else if (chunks_done == 0) {
             throw Error{AMPLI_E_INVALID, "no sample could be read from " + a.germline_dir};
         }
-        std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
-        std::vector<uint8_t> code((size_t)P * 4), gp((size_t)P * 4);
         int32_t flags = 0;
         dev.download(rate.data(), d_rate, rate.size());
         dev.download(code.data(), d_code, code.size());

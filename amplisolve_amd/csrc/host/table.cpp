@@ -107,16 +107,27 @@ void write_error_table(const Panel &panel, const float *rate, const uint8_t *cod
     size_t longest_chrom = 0, longest_ref = 0;
     for (auto &c : panel.chroms) longest_chrom = std::max(longest_chrom, c.size());
     for (auto &r : panel.ref_base) longest_ref = std::max(longest_ref, r.size());
-    // a row: chrom, position (<= 11), reference, YES/NO, 4 x "%f_%f" (each %f <= 48 characters for a finite float), 4 x "%g" (<= 13), 12 separators
+    // a row at its longest: chrom, position (<= 11), reference, YES/NO, 4 x "%f_%f" (each %f <= 48 characters for a finite
+    // float), 4 x "%g" (<= 13), 12 separators; a typical row is ~110 characters, so the slice buffer starts at 160 per row
+    // (uninitialised memory: zero-filling tens of MB cost more than the formatting) and grows if a row might not fit
     const size_t row_cap = longest_chrom + longest_ref + 11 + 3 + 4 * (2 * 48 + 1) + 4 * 16 + 16;
-    std::vector<std::string> part((size_t)n_threads);
+    struct Slice { char *base = nullptr; size_t len = 0; ~Slice() { free(base); } };
+    std::vector<Slice> part((size_t)n_threads);
     auto work = [&](int t) {
         const size_t i0 = n * (size_t)t / (size_t)n_threads, i1 = n * (size_t)(t + 1) / (size_t)n_threads;
-        std::string &buf = part[(size_t)t];
-        buf.resize((i1 - i0) * row_cap);
-        char *const base = &buf[0];
+        size_t cap = (i1 - i0) * (longest_chrom + longest_ref + 160) + row_cap;
+        char *base = (char *)malloc(cap);
+        if (!base) return; // reported below: a slice without a buffer
         char *q = base;
         for (size_t i = i0; i < i1; ++i) {
+            if ((size_t)(q - base) + row_cap > cap) {
+                const size_t used = (size_t)(q - base);
+                cap = cap + cap / 2 + row_cap;
+                char *nb = (char *)realloc(base, cap);
+                if (!nb) { free(base); return; }
+                base = nb;
+                q = base + used;
+            }
             const uint32_t p = panel.walk[i];
             const std::string &chrom = panel.chroms[panel.pos_chrom[p]];
             q = put_str(q, chrom.data(), chrom.size());
@@ -149,7 +160,8 @@ void write_error_table(const Panel &panel, const float *rate, const uint8_t *cod
             }
             *q++ = '\n';
         }
-        buf.resize((size_t)(q - base));
+        part[(size_t)t].base = base;
+        part[(size_t)t].len = (size_t)(q - base);
     };
     std::vector<std::thread> th;
     for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
@@ -158,7 +170,10 @@ void write_error_table(const Panel &panel, const float *rate, const uint8_t *cod
     std::ofstream out(path, std::ios::binary);
     if (!out) throw Error{AMPLI_E_INVALID, "cannot write " + path};
     out << kHeader << '\n';
-    for (const std::string &b : part) out.write(b.data(), (std::streamsize)b.size());
+    for (size_t t = 0; t < part.size(); ++t) {
+        if (!part[t].base && n * (t + 1) / part.size() > n * t / part.size()) throw Error{AMPLI_E_NOMEM, "out of memory formatting " + path};
+        out.write(part[t].base, (std::streamsize)part[t].len);
+    }
     out.close();
     if (out.fail()) throw Error{AMPLI_E_INVALID, "cannot write " + path};
 }
