@@ -102,6 +102,7 @@ HIP_SYMBOLS = {
     "ampli_comm_barrier": (C.c_int, [vp]),
     "ampli_pileup_count": (C.c_int, [vp, vp, vp, i64, vp, i64, i32, i32, vp, vp]),
     "ampli_score_batch": (C.c_int, [vp, vp, vp, vp, i64, vp, vp]),
+    "ampli_score_dense_batch": (C.c_int, [vp, vp, vp, vp, i64, vp]),
     "ampli_roundtrip_batch": (C.c_int, [vp, vp, i64, vp]),
     "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),
     "ampli_synth_ref": (C.c_int, [vp, vp, i64, u64]),
@@ -142,6 +143,7 @@ HOST_SYMBOLS = {
     "ampli_host_prefilter_nocall": (C.c_int, [i32, i32, f32]),
     "ampli_host_prefilter_skip_f32": (C.c_int, [i32, i32, f32]),
     "ampli_host_drain_score_batch": (None, [vp, vp, vp, i64, vp, vp]),
+    "ampli_host_dense_score_batch": (None, [vp, vp, vp, i64, vp]),
     "ampli_host_last_error": (C.c_char_p, []),
     "ampli_host_cohort_load": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]),
     "ampli_host_cohort_load_shard": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, i32, i32, C.POINTER(vp)]),

@@ -443,6 +443,14 @@ class Context:
         self._check(self.lib.ampli_score_batch(self.h, _ptr(k), _ptr(rd), _ptr(err), n, _ptr(q), _ptr(p)))
         return q, p
 
+    def score_dense_batch(self, k, rd, err):
+        """Q by the all-scores mode's scorer (ampli_poisson_score_dense)"""
+        import torch
+
+        q = torch.empty(k.numel(), dtype=torch.float64, device=self.device)
+        self._check(self.lib.ampli_score_dense_batch(self.h, _ptr(k), _ptr(rd), _ptr(err), k.numel(), _ptr(q)))
+        return q
+
     def roundtrip_batch(self, x):
         import torch
 

@@ -36,7 +36,10 @@ struct ampli_ctx {
     int n_cu = 256;
     // poisson_call tuning (ampli_set_poisson_tuning; 0 = default)
     int pc_rows_per_wave = 0, pc_drain_blocks = 0;
+    // kf_lgamma at the integers 0 .. AMPLI_LGTAB - 1, filled by the device's own ampli_kf_lgamma (the all-scores mode's scorer)
+    double *d_lgtab = nullptr;
 };
+constexpr int AMPLI_LGTAB = 4096;
 
 #define HIP_TRY(ctx, expr)                                                                        \
     do {                                                                                          \

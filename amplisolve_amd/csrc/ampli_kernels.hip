@@ -102,6 +102,7 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->queue_n) (void)hipFree(ctx->queue_n);
+    if (ctx->d_lgtab) (void)hipFree(ctx->d_lgtab);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->ev_stream_done) (void)hipEventDestroy(ctx->ev_stream_done);
     if (ctx->ev_drain_done) (void)hipEventDestroy(ctx->ev_drain_done);
@@ -1300,7 +1301,7 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
     const int T, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
     const unsigned char *__restrict__ ref_code, const int cov,
     unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
-    unsigned long long *__restrict__ n_calls, double *__restrict__ qd, float *__restrict__ afd)
+    unsigned long long *__restrict__ n_calls, double *__restrict__ qd, float *__restrict__ afd, const double *__restrict__ lgtab)
 {
     constexpr int RB = rec_bytes_of<LAY>();
     const long long R = P + E;
@@ -1359,8 +1360,10 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
                     if (!(q_fw >= 5.0 - AMPLI_CALL_GATE_EPS)) continue;
                     q_bw = ampli_poisson_score(k_bw, d_bw, th[1][nt]);
                 } else {
-                    q_fw = ampli_poisson_score(k_fw, d_fw, th[0][nt]);
-                    q_bw = ampli_poisson_score(k_bw, d_bw, th[1][nt]);
+                    // every score of every record, as the reference evaluates them (VC:895-896) -- through the integer-count
+                    // form of the same scorer (csrc/ampli_math.h, ampli_poisson_score_dense)
+                    q_fw = ampli_poisson_score_dense(k_fw, d_fw, th[0][nt], lgtab, AMPLI_LGTAB);
+                    q_bw = ampli_poisson_score_dense(k_bw, d_bw, th[1][nt], lgtab, AMPLI_LGTAB);
                     if (qd) { qd[o * 8 + nt * 2 + 0] = q_fw; qd[o * 8 + nt * 2 + 1] = q_bw; }
                 }
                 const bool is_call = covok && q_fw >= 5 && q_bw >= 5; // VC:898
@@ -1632,6 +1635,18 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
             }
         }
     }
+}
+
+__global__ void lgamma_table_kernel(double *t, const int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = ampli_kf_lgamma((double)i);
+}
+
+__global__ void score_dense_batch_kernel(const int *k, const int *rd, const float *err, const long long n, double *q, const double *lgtab)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q[i] = ampli_poisson_score_dense(k[i], rd[i], err[i], lgtab, AMPLI_LGTAB);
 }
 
 __global__ void score_batch_kernel(const int *k, const int *rd, const float *err, const long long n, double *q, double *pv)
@@ -2147,6 +2162,15 @@ extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc
     return launch_finalize(ctx, to_ptrs(d_acc), P, C, (int)cov, fo);
 }
 
+static int ensure_lgtab(ampli_ctx *ctx)
+{
+    if (ctx->d_lgtab) return AMPLI_OK;
+    if (is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "the lgamma table would have to be built while capturing: run the sequence once first");
+    if (hipMalloc((void **)&ctx->d_lgtab, sizeof(double) * AMPLI_LGTAB) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "lgamma table hipMalloc failed");
+    hipLaunchKernelGGL(lgamma_table_kernel, dim3((AMPLI_LGTAB + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_lgtab, AMPLI_LGTAB);
+    return check_launch(ctx, "lgamma_table_kernel");
+}
+
 static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, const float *d_thr, const long long thr_L, const size_t thr_bb,
                              const uint8_t *d_ref_code, int32_t cov, int32_t mode, uint8_t *d_call_mask, ampli_call *d_calls, int64_t capacity,
                              unsigned long long *d_n_calls, double *d_q, float *d_af)
@@ -2179,8 +2203,9 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
     hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                  \
                        (long long)E, d_ext_pos, (int)T, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, d_call_mask, d_calls,       \
                        (long long)capacity,                                                                                     \
-                       d_n_calls, d_q, d_af)
+                       d_n_calls, d_q, d_af, (const double *)ctx->d_lgtab)
     if (mode == AMPLI_POISSON_FULL) {
+        { int rcl = ensure_lgtab(ctx); if (rcl) return rcl; }
         if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U24);
         else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U16);
         else AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_I32);
@@ -2311,6 +2336,16 @@ extern "C" int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32
     hipLaunchKernelGGL(score_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_rd, d_err,
                        (long long)n, d_q, d_p);
     return check_launch(ctx, "score_batch_kernel");
+}
+
+extern "C" int ampli_score_dense_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err, int64_t n, double *d_q)
+{
+    if (!ctx || !d_k || !d_rd || !d_err || !d_q || n <= 0) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rcl = ensure_lgtab(ctx); if (rcl) return rcl; }
+    hipLaunchKernelGGL(score_dense_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_rd, d_err,
+                       (long long)n, d_q, (const double *)ctx->d_lgtab);
+    return check_launch(ctx, "score_dense_batch_kernel");
 }
 
 extern "C" int ampli_roundtrip_batch(ampli_ctx *ctx, const float *d_in, int64_t n, float *d_out)

@@ -198,6 +198,88 @@ AMPLI_FN double ampli_poisson_score(int32_t k, int32_t rd, float err)
     return ampli_q_from_p(ampli_poisson_p(k, rd, err));
 }
 
+// ---------------------------------------------------------------------------
+// The all-scores mode's scorer (round 4): the same Q as ampli_poisson_score, to rounding, for what that mode feeds it --
+// s = k is always an INTEGER count -- at about a third of the instructions:
+//   * kf_lgamma(s), kf_lgamma(s + 1) come from a table of the Lanczos form's own values at the integers (lgtab[n] =
+//     ampli_kf_lgamma(n), filled by the same function on the same device, so bit-identical to calling it; NULL or an index
+//     beyond ntab: the function itself): 8 divisions + 2 logarithms less per score;
+//   * the series branch is the division-free form of the drain kernel (ampli_kf_gammap_series_nodiv);
+//   * the continued fraction (VC:3733-3752) is evaluated through its convergents, f_j = A_j / B_j with
+//       A_j = b_j A_{j-1} + a_j A_{j-2},  B_j = b_j B_{j-1} + a_j B_{j-2},  a_j = j (s - j),  b_j = 2j + 1 + z - s
+//     (modified Lentz keeps C_j = A_j / A_{j-1} and D_j = B_{j-1} / B_j and pays two divisions per step; the product of the
+//     C_j D_j it accumulates IS A_j / B_j).  The reference leaves the loop once |C_j D_j - 1| < 1e-14 or after 99 steps, and
+//     for an integer s at j = s at the latest (a_s = 0 makes the step the identity); all three exits are kept.  In this
+//     branch z > s >= 1, so every a_j up to the exit and every b_j is positive and the KF_TINY guards never fire;
+//   * log(sum) / log(f) are not taken: the prefactor exp(s log z - z - lgamma) is multiplied / divided instead.
+// Differences from the literal scorer: rounding (~1e-13 relative on p, measured in tests/test_math_host.py); the contract
+// is 1e-6, and a Q within 1e-6 of a gate is re-decided by the host in the reference's own arithmetic either way.
+// ---------------------------------------------------------------------------
+AMPLI_FN double ampli_lgamma_int(int n, const double *lgtab, int ntab)
+{
+    return (lgtab && n < ntab) ? lgtab[n] : ampli_kf_lgamma((double)n);
+}
+
+// P(s, z) by the series, z <= s (the branch kf_gammaq takes for z <= 1 or z < s), prefactor given
+AMPLI_FN double ampli_gammap_series_int(double s, double z, double prefactor /* exp(s log z - z - lgamma(s + 1)) */)
+{
+    double A = 1., D = 1., zp = 1., t = s;
+    for (int blk = 0; blk < 7; ++blk) {
+        const int len = blk < 6 ? 16 : 3;
+        for (int i = 0; i < len; ++i) {
+            t += 1.;
+            zp *= z;
+            A = fma(A, t, zp);
+            D *= t;
+        }
+        if (zp < A * 8.673617379884035e-19) break; // see ampli_kf_gammap_series_nodiv
+        int e;
+        (void)frexp(D, &e);
+        A = ldexp(A, -e); D = ldexp(D, -e); zp = ldexp(zp, -e);
+    }
+    return prefactor * (A / D);
+}
+
+// Q(s, z) by the continued fraction for an integer s = k, z > s, prefactor given
+AMPLI_FN double ampli_gammaq_cf_int(int k, double z, double prefactor /* exp(s log z - z - lgamma(s)) */)
+{
+    const double s = (double)k;
+    double A1 = 1. + z - s, A2 = 1., B1 = 1., B2 = 0.; // f_0 = b_0; A_{-1} = 1, B_{-1} = 0, B_0 = 1
+    const int J = k - 1 < 99 ? k - 1 : 99;             // j = s is the identity step; the reference's cap is j < 100
+    for (int j = 1; j <= J; ++j) {
+        const double a = (double)j * (s - j), b = (double)((j << 1) + 1) + z - s;
+        const double A0 = fma(b, A1, a * A2), B0 = fma(b, B1, a * B2);
+        const double num = A0 * B1, den = A1 * B0; // C_j D_j = num / den, both positive
+        A2 = A1; A1 = A0; B2 = B1; B1 = B0;
+        if (fabs(num - den) < 1e-14 * den) break;
+        if ((j & 7) == 0) { // a, b < 2^33: eight steps stay far inside the double range
+            int e;
+            (void)frexp(A1, &e);
+            A1 = ldexp(A1, -e); A2 = ldexp(A2, -e); B1 = ldexp(B1, -e); B2 = ldexp(B2, -e);
+        }
+    }
+    return prefactor * B1 / A1; // exp(...) / f, f = A_j / B_j  (VC:3751)
+}
+
+AMPLI_FN double ampli_poisson_score_dense(int32_t k, int32_t rd, float err, const double *lgtab, int ntab)
+{
+    if (err == -1) return -888.0;   // VC:3844-3849
+    if (err == 0) err = 0.0010008f; // VC:3852-3856
+    if (k == 0) return 0.0;         // VC:3858-3861: p = 1 -> Q = 0 (VC:3873-3876)
+    if (k < 0) return ampli_q_from_p(1 - ampli_kf_gammaq((double)k, (double)rd * err)); // not a count: the literal path
+    const double s = (double)k, z = (double)rd * err; // VC:3864: double * float
+    const double lz = log(z);
+    double p;
+    if (z <= 1. || z < s) { // VC:3728
+        if (!(z > 0)) return ampli_q_from_p(1 - ampli_kf_gammaq(s, z)); // z <= 0 or NaN: whatever the literal arithmetic gives
+        const double P = ampli_gammap_series_int(s, z, exp(s * lz - z - ampli_lgamma_int(k + 1, lgtab, ntab)));
+        p = 1 - (1. - P); // VC:3865 on top of VC:3728
+    } else {
+        p = 1 - ampli_gammaq_cf_int(k, z, exp(s * lz - z - ampli_lgamma_int(k, lgtab, ntab)));
+    }
+    return ampli_q_from_p(p);
+}
+
 // Exact-decision bound used by AMPLI_POISSON_PREFILTER: when k <= m the
 // reference's own scorer returns Q < 5 (P(X >= k) > 0.31 for k <= mean; checked
 // exhaustively against the scorer incl. its iteration caps in

@@ -48,6 +48,10 @@ extern "C" void ampli_host_drain_score_batch(const int32_t *k, const int32_t *rd
         if (q) q[i] = ampli_q_from_p(pv);
     }
 }
+extern "C" void ampli_host_dense_score_batch(const int32_t *k, const int32_t *rd, const float *err, int64_t n, double *q)
+{
+    for (int64_t i = 0; i < n; ++i) q[i] = ampli_poisson_score_dense(k[i], rd[i], err[i], nullptr, 0);
+}
 extern "C" void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *out)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = ampli_af_limit(d[i]);

@@ -413,6 +413,10 @@ int ampli_comm_barrier(ampli_comm *c);
  * p[i] = 1 - kf_gammaq(k, rd*err) (VC:3834-3884).  Either output may be NULL. */
 int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err,
                       int64_t n, double *d_q, double *d_p);
+/* the scorer of the all-scores mode (AMPLI_POISSON_FULL) for the same tests: the integer-count form of the same recipe --
+ * lgamma from a table of the Lanczos form's own values, division-free series and continued fraction (csrc/ampli_math.h,
+ * ampli_poisson_score_dense); q[i] equals ampli_score_batch's to rounding (~1e-13 relative on p) */
+int ampli_score_dense_batch(ampli_ctx *ctx, const int32_t *d_k, const int32_t *d_rd, const float *d_err, int64_t n, double *d_q);
 /* text round trip on the device for known-answer tests: out[i] = stof(sprintf("%f", in[i])) */
 int ampli_roundtrip_batch(ampli_ctx *ctx, const float *d_in, int64_t n, float *d_out);
 

@@ -37,6 +37,8 @@ int32_t ampli_host_af_limit(int32_t d);
 void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *out);
 int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err);
 int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err); /* the streaming kernel's fp32 form */
+/* the all-scores mode's scorer (ampli_poisson_score_dense, csrc/ampli_math.h) on the host, lgamma computed: Q */
+void ampli_host_dense_score_batch(const int32_t *k, const int32_t *rd, const float *err, int64_t n, double *q);
 /* the drain kernel's scorer (division-free series, csrc/ampli_math.h) for items with k > rd*err > 0: Q and p */
 void ampli_host_drain_score_batch(const int32_t *k, const int32_t *rd, const float *err, int64_t n, double *q, double *p);
 

@@ -388,6 +388,15 @@ def test_device_scorer_against_the_reference_functions_directly(ctx):
     m = ~special
     assert np.max(np.abs(q[m] - want[m]) / np.maximum(np.abs(want[m]), 1e-300)) <= Q_TOL
     assert np.array_equal(q >= 5, want >= 5)
+    # the scorer of the all-scores mode (AMPLI_POISSON_FULL since round 4: integer-count form of the same recipe) against the
+    # same reference values: specials identical, Q within 1e-6 relative, every Q >= 5 decision identical
+    qd = ctx.score_dense_batch(_t(k), _t(rd), _t(err)).cpu().numpy()
+    assert np.array_equal(qd[special], want[special])
+    assert np.max(np.abs(qd[m] - want[m]) / np.maximum(np.abs(want[m]), 1e-300)) <= Q_TOL
+    assert np.array_equal(qd >= 5, want >= 5)
+    # and p itself within the north star's 1e-6 (absolute and relative): p = 10^(-Q/10) where Q is not clamped
+    pw, pd = 10.0 ** (-want[m] / 10), 10.0 ** (-qd[m] / 10)
+    assert np.max(np.abs(pd - pw)) <= 1e-6 and np.max(np.abs(pd - pw) / pw) <= 1e-6
 
 
 @pytest.mark.parametrize("P,T", [(1, 1), (255, 3), (257, 5), (3000, 8)])

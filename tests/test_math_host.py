@@ -158,6 +158,51 @@ def test_division_free_series_of_the_drain_kernel_is_the_reference_series():
     assert np.max(np.abs(q[fin] - qo[fin])) < 1e-7
 
 
+def test_dense_scorer_of_the_all_scores_mode_is_the_reference_scorer():
+    """AMPLI_POISSON_FULL scores every (record, alt, strand) with the integer-count form of the reference's recipe (round 4:
+    lgamma at the integers, division-free series, continued fraction through its convergents; csrc/ampli_math.h).  Against the
+    oracle's literal scorer -- itself bit-identical to the reference's compiled functions -- on the reference's own golden grid,
+    on counts around the mean at every depth (both branches of kf_gammaq, the identity step j = s of the continued fraction,
+    the 99-step caps of both loops, k and m far beyond 100) and on the special codes: p within 1e-11 relative + one step of
+    1 - (1 - P) (the contract is 1e-6), the specials identical, the Q >= 5 / >= 20 / = 100 decisions identical outside 1e-9 of a gate."""
+    import os
+
+    H = host_lib()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vc_scorer_reference.npz"))
+    rng = np.random.default_rng(21)
+    ks, rds, es = [g["k"].astype(np.int64)], [g["rd"].astype(np.int64)], [g["err"].astype(np.float64)]
+    for err in (0.0, -1.0, 0.0001, 0.0005, 0.002, 0.002189, 0.0035, 0.01, 0.02, 0.05, 0.25, 0.9):
+        for scale in (1, 5, 50, 300, 1000, 2500, 25000, 400000, 3_000_000, 16_000_000, 500_000_000):
+            rd = rng.integers(max(1, scale // 2), scale * 2 + 1, 400)
+            m = rd * float(np.float32(err if err > 0 else 0.0010008))
+            for f in (0.0, 0.3, 0.8, 0.97, 1.0, 1.03, 1.3, 3.0, 10.0):
+                k = np.maximum(np.floor(m * f).astype(np.int64) + rng.integers(-2, 3, rd.size), 0)
+                ok = k < (1 << 31) - 1
+                ks.append(k[ok]); rds.append(rd[ok]); es.append(np.full(int(ok.sum()), err))
+    # small counts x small means: what a 2000x panel holds
+    kk, mm = np.meshgrid(np.arange(0, 40), np.arange(1, 120), indexing="ij")
+    ks.append(kk.ravel()); rds.append(mm.ravel() * 50); es.append(np.full(kk.size, 0.002))
+    k = np.concatenate(ks).astype(np.int32)
+    rd = np.concatenate(rds).astype(np.int32)
+    e = np.concatenate(es).astype(np.float32)
+    q = np.empty(k.size, np.float64)
+    H.ampli_host_dense_score_batch(k.ctypes.data_as(C.c_void_p), rd.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p), k.size, q.ctypes.data_as(C.c_void_p))
+    qo, po = orc.score_batch(k, rd, e)
+    assert k.size > 400_000
+    special = (qo == -888) | (qo == 100) | (qo == 0) | np.isnan(qo)
+    assert np.array_equal(q[qo == -888], qo[qo == -888]) and np.array_equal(np.isnan(q), np.isnan(qo))
+    for thr in (5.0, 20.0, 100.0):
+        far = np.abs(qo - thr) > 1e-9
+        assert np.array_equal((q >= thr)[far & ~np.isnan(qo)], (qo >= thr)[far & ~np.isnan(qo)]), thr
+    assert np.array_equal(q[qo == 0] == 0, np.ones(int((qo == 0).sum()), bool))
+    fin = ~special & (q != 100) & (q != 0)
+    # Q = -10 log10 p: |dQ| = 4.34 |dp| / p
+    pq = 10.0 ** (-q[fin] / 10)
+    excess = np.abs(pq - po[fin]) - (1e-11 * po[fin] + 2.3e-16)
+    assert np.max(excess) <= 0, (k[fin][np.argmax(excess)], rd[fin][np.argmax(excess)], e[fin][np.argmax(excess)], np.max(excess))
+    assert np.max(np.abs(q[fin] - qo[fin])) < 1e-7
+
+
 def test_decision_guard_is_the_reference_operation_sequence():
     """The host re-evaluates calls within 1e-6 of a gate with the reference's own sequence (double kf_gammaq, long double
     log10; csrc/host/annotate.cpp).  On the golden grid produced by the reference's compiled scorer it must return the very
