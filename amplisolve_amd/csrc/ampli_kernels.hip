@@ -1444,8 +1444,13 @@ __device__ __forceinline__ void pc_flush(const PcItem *__restrict__ st, const in
     if (fit < count && lane == 0) atomicOr(flags, AMPLI_FLAG_QUEUE_OVERFLOW);
 }
 
+// Seven waves per SIMD (72 VGPRs), not eight: at 64 VGPRs the compiler spilled 7-23 registers to scratch, and every wave's
+// spill stores are HBM writes -- r03's PMC showed them as WRITE_SIZE 17.1 MB against a 9.6 MB mask ("the mask touched twice"
+// of VERDICT r03; the mask is written once).  Round 4, tools/ps_spill_ab.sh: 8 waves with spills 47.2-47.8 us per call, 7 waves
+// without 45.4-45.7 us (uint16 records; 24-byte records 61 -> 59.7 us); six waves (80 VGPRs) gain nothing more and lose 10 %
+// with 24-byte records.
 template <int LAY, bool IRR>
-__global__ __launch_bounds__(256, 8) void poisson_stream_kernel(
+__global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
     const RecView rv, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
     const int T, const int rows_per_wave, const unsigned gy, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
     const unsigned char *__restrict__ ref_code,

@@ -34,6 +34,11 @@ V = {
     # exec-mask block -- s_and_saveexec / s_or exec / s_cbranch_execz around three vector instructions)
     "ps_branchfree": [("            const bool skip_fw = exact && (unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)fw[nt] <= c_fw * te[0][nt];\n            const bool skip_bw = exact && (unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT && (float)bw[nt] <= c_bw * te[1][nt];\n            if (live && nt != ref && !skip_fw && !skip_bw) pushmask |= 1u << nt;",
                        "            const int skip_fw = (int)exact & (int)((unsigned)fw[nt] < (unsigned)AMPLI_COUNT_LIMIT) & (int)((float)fw[nt] <= c_fw * te[0][nt]);\n            const int skip_bw = (int)exact & (int)((unsigned)bw[nt] < (unsigned)AMPLI_COUNT_LIMIT) & (int)((float)bw[nt] <= c_bw * te[1][nt]);\n            pushmask |= (unsigned)((int)live & (int)(nt != ref) & (skip_fw ^ 1) & (skip_bw ^ 1)) << nt;")],
+    # poisson_stream at 7 / 6 waves per SIMD (72 / 80 VGPRs): the shipped 8-wave build (64 VGPRs) spills 7-23 registers to scratch,
+    # and every wave's spill stores are HBM writes (round 4: that is the "mask touched twice" of the r03 WRITE_SIZE, 17.1 MB vs 9.6 MB)
+    # (shipped since round 4: 7; these rebuild the comparison)
+    "ps_lb8": [("template <int LAY, bool IRR>\n__global__ __launch_bounds__(256, 7) void poisson_stream_kernel(", "template <int LAY, bool IRR>\n__global__ __launch_bounds__(256, 8) void poisson_stream_kernel(")],
+    "ps_lb6": [("template <int LAY, bool IRR>\n__global__ __launch_bounds__(256, 7) void poisson_stream_kernel(", "template <int LAY, bool IRR>\n__global__ __launch_bounds__(256, 6) void poisson_stream_kernel(")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }

@@ -17,10 +17,11 @@ ctx = Context(0)
 normals = ctx.synth_fill(P, S, seed=SEED, depth=2000)
 tumours = ctx.synth_fill(P, T, seed=SEED, depth=2000, tumour=True)
 ref_code = ctx.synth_ref(P, seed=SEED)
-n24, _ = ctx.pack24(normals)
-t24, _ = ctx.pack24(tumours)
+LAYOUT = os.environ.get("PP_LAYOUT", "u24")  # record layout the launches read
+n24, _ = ctx.pack(normals, LAYOUT)
+t24, _ = ctx.pack(tumours, LAYOUT)
 del normals, tumours
-ctx.set_record_layout("u24")
+ctx.set_record_layout(LAYOUT)
 fin = ctx.error_estimate(n24, P, 0.002, 100)
 ctx.set_poisson_tuning(rows, blocks)
 res = ctx.poisson_call(t24, P, fin.thr, ref_code, 100, capacity=1 << 20)
