@@ -168,7 +168,7 @@ inline bool parse_int(const char *&p, const char *e, int64_t &v)
 // is the header (EE:1113, VC:721).  fw = X - Xrs (EE:1155-1158).  The first line of a panel position goes straight
 // into dst (this sample's row of P records in `layout`, pre-filled as absent by this function); further lines of the
 // same position (overlapping amplicons) are returned as extras.  line: optional [P] data-line index of the primaries.
-void parse_file(const Panel &panel, const std::string &path, int layout, char *dst, int32_t *line, FileResult &out)
+void parse_file_text(const Panel &panel, const std::string &path, int layout, char *dst, int32_t *line, FileResult &out)
 {
     const int64_t P = panel.P();
     const size_t rb = record_bytes(layout);
@@ -274,6 +274,183 @@ void parse_file(const Panel &panel, const std::string &path, int layout, char *d
     close(fd);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The binary record cache (opt-in: AMPLISOLVE_CACHE=1): `<file>.aseqbin` beside each `.PILEUP.ASEQ` holds what
+// parse_file_text produced for it against THIS panel -- the P packed records in the narrowest layout the file's counts fit, the
+// data-line index of each, the extra occurrences, the lines with their own RD column and the line statistics -- so that a
+// repeated run over the same files (another C value, another coverage cutoff, the calling step after a changed error table)
+// skips the text.  A cache file is used only if its header matches: format version, the panel's digest (chromosome names
+// and coordinates of its P positions, in order), P, and the text file's size and modification time (ns); anything else --
+// also a truncated or unreadable file -- falls back to the text and rewrites it.  Outputs are byte-identical with and without
+// (tests/test_stream_ingest.py, tests/test_gpu_cli.py).  Written through a temporary name + rename; an unwritable directory
+// just means no cache.  `*.aseqbin` does not match the `*.ASEQ` of the file list (EE:556), the reference's or ours.
+// ---------------------------------------------------------------------------------------------------------
+struct CacheHeader {
+    char magic[8]; // "AMPLBIN1"
+    uint32_t layout, n_extras, n_irregular, reserved;
+    int64_t P;
+    uint64_t panel_digest;
+    int64_t text_size, text_mtime_ns;
+    int64_t n_lines, n_off, n_irregular_lines, n_malformed, max_count;
+};
+static_assert(sizeof(CacheHeader) == 96, "cache header layout");
+
+bool cache_enabled()
+{
+    const char *e = getenv("AMPLISOLVE_CACHE");
+    return e && *e && !(e[0] == '0' && e[1] == 0);
+}
+
+inline int layout_width(int lay) { return lay == AMPLI_RECORDS_U16 ? 0 : (lay == AMPLI_RECORDS_U24 ? 1 : 2); }
+inline int layout_needed(int64_t m) { return m <= 65534 ? AMPLI_RECORDS_U16 : (m <= 0xFFFFFE ? AMPLI_RECORDS_U24 : AMPLI_RECORDS_I32); }
+
+// one record of `layout` -> the eight int32 counts of the interchange layout (absent: rec[0] = AMPLI_ABSENT)
+inline void get_record(int layout, const char *src, int32_t rec[8])
+{
+    if (layout == AMPLI_RECORDS_U16) {
+        uint16_t v[8];
+        memcpy(v, src, 16);
+        for (int j = 0; j < 8; ++j) rec[j] = v[j];
+        if (v[0] == 0xFFFF) rec[0] = AMPLI_ABSENT;
+    } else if (layout == AMPLI_RECORDS_U24) {
+        const unsigned char *b = (const unsigned char *)src;
+        for (int j = 0; j < 8; ++j) rec[j] = (int32_t)(b[3 * j] | (b[3 * j + 1] << 8) | (b[3 * j + 2] << 16));
+        if (rec[0] == 0xFFFFFF) rec[0] = AMPLI_ABSENT;
+    } else {
+        memcpy(rec, src, 32);
+    }
+}
+
+// records of one layout into another that is wide enough for them (absent markers translated)
+void convert_records(int from, const char *src, int to, char *dst, size_t n)
+{
+    if (from == to) { memcpy(dst, src, n * record_bytes(to)); return; }
+    const size_t fb = record_bytes(from), tb = record_bytes(to);
+    const int32_t absent_to = to == AMPLI_RECORDS_U24 ? 0xFFFFFF : (to == AMPLI_RECORDS_U16 ? 0xFFFF : AMPLI_ABSENT);
+    for (size_t i = 0; i < n; ++i) {
+        int32_t rec[8];
+        get_record(from, src + i * fb, rec);
+        if (rec[0] == AMPLI_ABSENT) rec[0] = absent_to;
+        put_record(to, dst + i * tb, rec);
+    }
+}
+
+bool stat_text(const std::string &path, int64_t &size, int64_t &mtime_ns)
+{
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return false;
+    size = (int64_t)st.st_size;
+    mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+    return true;
+}
+
+// true: dst / line / out hold what parse_file_text would have produced (out.overflows set when the file needs wider records
+// than `layout`, exactly as the text parser reports it)
+bool cache_load(const Panel &panel, uint64_t digest, const std::string &path, int layout, char *dst, int32_t *line, FileResult &out)
+{
+    int64_t tsize, tmtime;
+    if (!stat_text(path, tsize, tmtime)) return false;
+    const std::string cpath = path + ".aseqbin";
+    const int fd = open(cpath.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(CacheHeader)) { close(fd); return false; }
+    const size_t len = (size_t)st.st_size;
+    const char *base = (const char *)mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) return false;
+    bool ok = false;
+    CacheHeader h;
+    memcpy(&h, base, sizeof h);
+    const int64_t P = panel.P();
+    if (memcmp(h.magic, "AMPLBIN1", 8) == 0 && h.P == P && h.panel_digest == digest && h.text_size == tsize && h.text_mtime_ns == tmtime &&
+        (h.layout == AMPLI_RECORDS_U16 || h.layout == AMPLI_RECORDS_U24 || h.layout == AMPLI_RECORDS_I32) && h.reserved == 0) {
+        const size_t rb = record_bytes((int)h.layout);
+        const size_t need = sizeof h + (size_t)P * rb + (size_t)P * sizeof(int32_t) + (size_t)h.n_extras * sizeof(Extra) + (size_t)h.n_irregular * sizeof(Irregular);
+        if (need == len) {
+            out.n_lines = h.n_lines; out.n_off = h.n_off; out.n_irregular = h.n_irregular_lines; out.n_malformed = h.n_malformed;
+            out.max_count = h.max_count;
+            if (layout_width((int)h.layout) > layout_width(layout)) {
+                out.overflows = true; // the chunk is packed again, wider (ChunkStream::Impl::fill)
+            } else {
+                const char *q = base + sizeof h;
+                convert_records((int)h.layout, q, layout, dst, (size_t)P);
+                q += (size_t)P * rb;
+                if (line) memcpy(line, q, (size_t)P * sizeof(int32_t));
+                q += (size_t)P * sizeof(int32_t);
+                out.extras.resize(h.n_extras);
+                if (h.n_extras) memcpy(out.extras.data(), q, (size_t)h.n_extras * sizeof(Extra));
+                q += (size_t)h.n_extras * sizeof(Extra);
+                out.irregular.resize(h.n_irregular);
+                if (h.n_irregular) memcpy(out.irregular.data(), q, (size_t)h.n_irregular * sizeof(Irregular));
+            }
+            ok = true;
+        }
+    }
+    munmap((void *)base, len);
+    return ok;
+}
+
+void cache_store(const Panel &panel, uint64_t digest, const std::string &path, int layout, const char *recs, const int32_t *line, const FileResult &r)
+{
+    int64_t tsize, tmtime;
+    if (!stat_text(path, tsize, tmtime)) return;
+    const int64_t P = panel.P();
+    CacheHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "AMPLBIN1", 8);
+    h.layout = (uint32_t)layout_needed(r.max_count); // the narrowest layout the file fits, whatever the chunk was packed in
+    h.n_extras = (uint32_t)r.extras.size(); h.n_irregular = (uint32_t)r.irregular.size();
+    h.P = P; h.panel_digest = digest; h.text_size = tsize; h.text_mtime_ns = tmtime;
+    h.n_lines = r.n_lines; h.n_off = r.n_off; h.n_irregular_lines = r.n_irregular; h.n_malformed = r.n_malformed; h.max_count = r.max_count;
+    std::vector<char> narrow;
+    const char *body = recs;
+    if ((int)h.layout != layout) {
+        narrow.resize((size_t)P * record_bytes((int)h.layout));
+        convert_records(layout, recs, (int)h.layout, narrow.data(), (size_t)P);
+        body = narrow.data();
+    }
+    char tag[64];
+    snprintf(tag, sizeof tag, ".tmp%ld_%lx", (long)getpid(), (unsigned long)std::hash<std::thread::id>()(std::this_thread::get_id()));
+    const std::string cpath = path + ".aseqbin", tmp = cpath + tag;
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return; // read-only data directory: no cache
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1 && fwrite(body, record_bytes((int)h.layout), (size_t)P, f) == (size_t)P &&
+              fwrite(line, sizeof(int32_t), (size_t)P, f) == (size_t)P;
+    if (ok && h.n_extras) ok = fwrite(r.extras.data(), sizeof(Extra), h.n_extras, f) == h.n_extras;
+    if (ok && h.n_irregular) ok = fwrite(r.irregular.data(), sizeof(Irregular), h.n_irregular, f) == h.n_irregular;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok || rename(tmp.c_str(), cpath.c_str()) != 0) unlink(tmp.c_str());
+}
+
+// One file through the cache when it is on and valid, else through the text parser (which then refreshes the cache)
+void parse_file(const Panel &panel, uint64_t digest, const std::string &path, int layout, char *dst, int32_t *line, FileResult &out)
+{
+    if (!cache_enabled()) { parse_file_text(panel, path, layout, dst, line, out); return; }
+    if (cache_load(panel, digest, path, layout, dst, line, out)) return;
+    out = FileResult();
+    std::vector<int32_t> own_line;
+    int32_t *ln = line;
+    if (!ln) { own_line.resize((size_t)panel.P()); ln = own_line.data(); } // the cache always carries the line indices (the calling step needs them)
+    parse_file_text(panel, path, layout, dst, ln, out);
+    if (out.error.empty() && !out.overflows) cache_store(panel, digest, path, layout, dst, ln, out);
+}
+
+// chromosome names + coordinates of the panel's positions, in order (FNV-1a): what a cache file was made against
+uint64_t panel_digest(const Panel &panel)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    for (const std::string &c : panel.chroms) { mix(c.data(), c.size()); mix("\0", 1); }
+    const int64_t P = panel.P();
+    mix(&P, sizeof P);
+    if (P) { mix(panel.pos_chrom.data(), (size_t)P * sizeof(int32_t)); mix(panel.pos_coord.data(), (size_t)P * sizeof(int32_t)); }
+    return h;
+}
+
 void *host_alloc(size_t bytes, bool &pinned, bool critical = true)
 {
     PhaseClock::Scope sc("pinned_alloc", critical);
@@ -341,6 +518,7 @@ struct ChunkStream::Impl {
     int n_threads = 1;
     bool keep_line = false;
     int per_chunk = 1, n_chunks = 0;
+    uint64_t digest = 0;                  // of the panel's positions: what a `.aseqbin` cache file must have been made against
     int floor_layout = AMPLI_RECORDS_U16; // narrowest layout the packer may use (AMPLISOLVE_RECORDS)
     int start_layout = AMPLI_RECORDS_U16; // layout the next chunk is packed in first
     std::vector<std::unique_ptr<Chunk>> slots;
@@ -383,7 +561,7 @@ struct ChunkStream::Impl {
             std::atomic<int> next{0};
             auto work = [&] {
                 for (int i; (i = next.fetch_add(1)) < n;)
-                    parse_file(panel, files[(size_t)lo + i].first, layout, (char *)c.prim + (size_t)i * P * rb,
+                    parse_file(panel, digest, files[(size_t)lo + i].first, layout, (char *)c.prim + (size_t)i * P * rb,
                                keep_line ? c.line_prim.data() + (size_t)i * P : nullptr, res[(size_t)i]);
             };
             const int nt = std::max(1, std::min(n_threads, n));
@@ -490,6 +668,7 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
     : im(new Impl(panel))
 {
     im->files = std::move(files);
+    if (cache_enabled()) im->digest = panel_digest(panel);
     // default: the cores this process may run on, at most 16 (one GPU's share of a node; AMPLISOLVE_THREADS overrides)
     if (n_threads <= 0) n_threads = std::min(16, (int)std::thread::hardware_concurrency());
     im->n_threads = std::max(1, n_threads);
@@ -586,6 +765,7 @@ void cohort_load(const Panel &panel, const std::string &dir, const std::string &
     for (auto &f : files) { out.paths.push_back(f.first); out.names.push_back(f.second); }
     out.P = P;
 
+    const uint64_t digest = cache_enabled() ? panel_digest(panel) : 0;
     std::vector<FileResult> res((size_t)S);
     std::vector<std::vector<int32_t>> prim((size_t)S), lines((size_t)S);
     if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
@@ -598,7 +778,7 @@ void cohort_load(const Panel &panel, const std::string &dir, const std::string &
             for (int s; (s = next.fetch_add(1)) < S;) {
                 prim[(size_t)s].resize((size_t)P * 8);
                 if (keep_line_no) lines[(size_t)s].resize((size_t)P);
-                parse_file(panel, out.paths[(size_t)s], AMPLI_RECORDS_I32, (char *)prim[(size_t)s].data(),
+                parse_file(panel, digest, out.paths[(size_t)s], AMPLI_RECORDS_I32, (char *)prim[(size_t)s].data(),
                            keep_line_no ? lines[(size_t)s].data() : nullptr, res[(size_t)s]);
             }
         });

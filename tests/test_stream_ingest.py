@@ -149,3 +149,98 @@ def test_irregular_lines_travel_as_a_side_list(tmp_path):
     s1 = co.names.index("S1")
     irr = sorted(tuple(int(v) for v in r) for r in chunks[0]["irregular"])
     assert irr == [(s1, 1, 0, 1000), (s1, co.P + 0, 1, 7)]
+
+
+def _chunks_signature(chunks):
+    """everything a consumer of the stream sees, as bytes"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for c in chunks:
+        h.update(repr((c["first"], c["n"], c["layout"], c["E"])).encode())
+        for k in ("prim", "ext", "dup_off", "ext_pos", "irregular"):
+            h.update(np.ascontiguousarray(c[k]).tobytes())
+        for k in ("line_prim", "line_ext"):
+            if c[k] is not None:
+                h.update(np.ascontiguousarray(c[k]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("panel", ["mini_edge", "irregular", "toy_subset"])
+def test_binary_record_cache_gives_the_same_stream(tmp_path, monkeypatch, panel):
+    """AMPLISOLVE_CACHE=1: the first pass over a directory leaves `<file>.aseqbin` beside every ASEQ file, the
+    second reads those instead of the text -- and hands over the very same chunks (records in every layout, positions listed
+    twice, lines with their own RD column, data-line indices, statistics).  A cache file is ignored when the text changed
+    (size / mtime), when it was made against another panel, or when it is damaged; then the text is parsed and the cache rewritten."""
+    import shutil
+
+    src = f"{G}/{panel}"
+    d = tmp_path / "N"
+    shutil.copytree(f"{src}/NORMAL", d)
+    bed, refb = f"{src}/panel.bed", f"{src}/refbases.txt"
+    monkeypatch.delenv("AMPLISOLVE_CACHE", raising=False)
+    co = HostCohort(bed, str(d), refbases_file=refb, keep_line_no=True)
+    plain = {kl: _chunks_signature(co.stream_chunks(str(d), chunk_bytes=1, threads=2, keep_line_no=kl)) for kl in (True, False)}
+    plain_stats = co.stats()
+    assert not [f for f in os.listdir(d) if f.endswith(".aseqbin")]
+    monkeypatch.setenv("AMPLISOLVE_CACHE", "1")
+    first = _chunks_signature(co.stream_chunks(str(d), chunk_bytes=1, threads=2, keep_line_no=False))  # written by a pass that did not ask for line indices
+    files = sorted(f for f in os.listdir(d) if f.endswith(".aseqbin"))
+    assert len(files) == co.S and first == plain[False]
+    stamp = {f: os.stat(d / f).st_mtime_ns for f in files}
+    for kl in (True, False):
+        for chunk_bytes, threads in ((1, 2), (1 << 30, 0)):
+            got = co.stream_chunks(str(d), chunk_bytes=chunk_bytes, threads=threads, keep_line_no=kl)
+            if chunk_bytes == 1:
+                assert _chunks_signature(got) == plain[kl]
+    assert {f: os.stat(d / f).st_mtime_ns for f in files} == stamp  # hits do not rewrite
+    # the dense loader (interchange layout, what the oracle comparisons read) goes through the same cache
+    co2 = HostCohort(bed, str(d), refbases_file=refb, keep_line_no=True)
+    assert np.array_equal(co2.recs, co.recs) and np.array_equal(co2.line_no, co.line_no) and co2.stats() == plain_stats
+    assert np.array_equal(co2.irregular, co.irregular)
+    # wider layouts out of a uint16 cache: AMPLISOLVE_RECORDS sets the narrowest layout the packer may use
+    for lay, code in (("u24", 2), ("i32", 0)):
+        monkeypatch.setenv("AMPLISOLVE_RECORDS", lay)
+        monkeypatch.setenv("AMPLISOLVE_CACHE", "0")
+        want = co.stream_chunks(str(d), chunk_bytes=1 << 30, keep_line_no=True)
+        monkeypatch.setenv("AMPLISOLVE_CACHE", "1")
+        got = co.stream_chunks(str(d), chunk_bytes=1 << 30, keep_line_no=True)
+        assert all(c["layout"] == code for c in got) and _chunks_signature(got) == _chunks_signature(want)
+    monkeypatch.delenv("AMPLISOLVE_RECORDS")
+    # invalidation: a changed text file, a damaged cache file, another panel
+    victim = sorted(f for f in os.listdir(d) if f.endswith(".ASEQ"))[0]
+    text = (d / victim).read_text().splitlines(keepends=True)
+    (d / victim).write_text("".join(text[:-1]))  # one data line less
+    co3 = HostCohort(bed, str(d), refbases_file=refb, keep_line_no=True)
+    assert co3.stats()["lines"] == plain_stats["lines"] - 1
+    assert os.stat(d / (victim + ".aseqbin")).st_mtime_ns != stamp[victim + ".aseqbin"]  # rewritten against the new text
+    other = sorted(files)[-1]
+    blob = (d / other).read_bytes()
+    (d / other).write_bytes(blob[: len(blob) // 2])
+    co4 = HostCohort(bed, str(d), refbases_file=refb, keep_line_no=True)
+    assert np.array_equal(co4.recs, co3.recs) and len((d / other).read_bytes()) == len(blob)
+    bed2 = tmp_path / "shifted.bed"
+    bed2.write_text("".join(l for i, l in enumerate(open(bed).read().splitlines(keepends=True)) if i != 1))  # one amplicon less: other positions
+    monkeypatch.setenv("AMPLISOLVE_CACHE", "0")
+    want = HostCohort(str(bed2), str(d), refbases_file=refb, keep_line_no=True)
+    monkeypatch.setenv("AMPLISOLVE_CACHE", "1")
+    got = HostCohort(str(bed2), str(d), refbases_file=refb, keep_line_no=True)
+    assert got.P == want.P != co.P and np.array_equal(got.recs, want.recs) and np.array_equal(got.line_no, want.line_no)
+
+
+def test_binary_record_cache_when_a_file_needs_wider_records(tmp_path, monkeypatch):
+    """A file whose counts need 24-bit fields, cached, then asked for in a chunk that is being packed as uint16: the cache answers
+    like the text parser (the chunk is packed again, wider), and the streams with and without the cache are the same bytes."""
+    files = {f"S{i}": [_line(p, 1000 + i, 2, 1, 3, (500 + i, 1, 0, 1)) for p in range(100, 105)] for i in range(5)}
+    files["S3"][2] = _line(102, 900_000, 3, 1, 2, (400_000, 1, 0, 1))  # beyond uint16
+    bed, refb, d = _write_panel(tmp_path, files)
+    monkeypatch.delenv("AMPLISOLVE_CACHE", raising=False)
+    co = HostCohort(bed, d, refbases_file=refb, keep_line_no=True)
+    want = co.stream_chunks(d, chunk_bytes=1, threads=1, keep_line_no=True)
+    monkeypatch.setenv("AMPLISOLVE_CACHE", "1")
+    made = co.stream_chunks(d, chunk_bytes=1, threads=1, keep_line_no=True)
+    again = co.stream_chunks(d, chunk_bytes=1, threads=1, keep_line_no=True)
+    assert _chunks_signature(made) == _chunks_signature(want) == _chunks_signature(again)
+    assert sorted({c["layout"] for c in again}) == [1, 2]  # uint16 chunks and the 24-bit one
+    one = co.stream_chunks(d, chunk_bytes=1 << 30, keep_line_no=True)
+    assert len(one) == 1 and one[0]["layout"] == 2
