@@ -79,6 +79,9 @@ HIP_SYMBOLS = {
     "ampli_set_slice_group": (C.c_int, [vp, i32, i32]),
     "ampli_slice_len": (i64, [i64, i32]),
     "ampli_slice_bytes": (C.c_int, [i64, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "ampli_slice_bytes_fmt": (C.c_int, [i64, i32, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ampli_slice_planes": (i32, [i32]),
+    "ampli_set_slice_format": (C.c_int, [vp, i32]),
     "ampli_error_reduce_sliced": (C.c_int, [vp, vp, i64, i64, vp, i32, i32, f32, i32, i32, vp, vp]),
     "ampli_acc_to_slices": (C.c_int, [vp, C.POINTER(AccTable), i32, vp, vp]),
     "ampli_error_finalize_slice": (C.c_int, [vp, i64, i32, i32, vp, vp, f32, i32, vp]),

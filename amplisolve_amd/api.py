@@ -192,6 +192,10 @@ class Context:
     def wait_calls(self):
         self._check(self.lib.ampli_wait_calls(self.h))
 
+    def set_slice_format(self, slim: bool):
+        """sums of the sliced exchange as 14 packed planes (slim) or 21 plain ones (ampli_set_slice_format)"""
+        self._check(self.lib.ampli_set_slice_format(self.h, 1 if slim else 0))
+
     def set_poisson_tuning(self, rows_per_wave: int = 0, drain_blocks: int = 0):
         """poisson_call launch shape (ampli_set_poisson_tuning); 0 = default.  Results do not depend on it."""
         self._check(self.lib.ampli_set_poisson_tuning(self.h, rows_per_wave, drain_blocks))

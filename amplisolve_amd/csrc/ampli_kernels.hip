@@ -617,8 +617,11 @@ struct FinOut {
     long long slice_len; // 0: `packed` is plane-major over the whole panel (above)
     double *sl_sums;     // [n_slices][21][slice_len]: the same 21 additive planes, slice-major
     float *sl_gm;        // [n_slices][8][slice_len]: germ-max first_af[4] (-1 = no qualifying record) | rest[4]
-    long long sl_group;  // batches per slice chunk (ampli_set_slice_group): chunk k of this batch starts k*sl_group*{21,8}*slice_len
+    long long sl_group;  // batches per slice chunk (ampli_set_slice_group): chunk k of this batch starts k*sl_group*{planes,8}*slice_len
                          //  elements behind sl_sums / sl_gm (which already point at this batch's part of chunk 0)
+    int sl_fmt;          // AMPLI_SLICE_WIDE: 21 planes, one value each; AMPLI_SLICE_SLIM: 14 planes, the integer planes packed
+    int sl_n;            //  (slim) number of slices = ranks whose contributions are summed: the range a shard may use of a packed field
+    int *sl_flags;       //  (slim) the context's flag word: AMPLI_FLAG_SLICE_RANGE when a value does not fit its share of a field
     int accumulate;      // the table already holds the state of the EARLIER samples: result = table (+) this launch
                          //  (streamed cohorts: one launch per uploaded chunk of samples, in visit order)
 };
@@ -636,22 +639,49 @@ __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, c
     pk[20 * P + p] = (double)a.nrec;
 }
 
+// The sums of the sliced exchange travel as doubles (ONE reduce-scatter, SUM, f64).  AMPLI_SLICE_WIDE: 21 planes, one value
+// each (snt 8 | srd 8 | cnt 4 | nrec 1) = 168 B per position.  AMPLI_SLICE_SLIM: 14 planes = 112 B: the integer planes share
+// doubles -- the two strands' depth sums of a nucleotide as lo + hi * 2^26, the counts as a + b * 2^17 (+ c * 2^34).  A sum of
+// doubles adds the fields independently and exactly as long as every field's TOTAL stays below its width (and the whole below
+// 2^53): each of the n shards may therefore use 1/n of a field's range, checked here where the shard's values are packed
+// (AMPLI_FLAG_SLICE_RANGE: the caller repeats the exchange in the wide format; config 4 on 8 GPUs uses < 3 % of the range).
+constexpr double SLIM_D = 67108864.0;        // 2^26: strand-depth sums
+constexpr double SLIM_C = 131072.0;          // 2^17: record counts
+constexpr double SLIM_C2 = 17179869184.0;    // 2^34
+__host__ __device__ constexpr int slice_planes(const int fmt) { return fmt == AMPLI_SLICE_SLIM ? 14 : 21; }
+
 // slice-major stores for the reduce-scatter merge: each destination rank's slice is one contiguous chunk
 __device__ __forceinline__ void lane_acc_store_sliced(const FinOut &o, const long long p, const LaneAcc &a)
 {
     const long long L = o.slice_len, k = p / L, q = p - k * L;
-    double *__restrict__ pk = o.sl_sums + (size_t)k * o.sl_group * 21 * L + q;
+    double *__restrict__ pk = o.sl_sums + (size_t)k * o.sl_group * slice_planes(o.sl_fmt) * L + q;
     float *__restrict__ gm = o.sl_gm + (size_t)k * o.sl_group * 8 * L + q;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         pk[(0 * 4 + nt) * L] = a.snt[0][nt];
         pk[(1 * 4 + nt) * L] = a.snt[1][nt];
-        pk[(8 + 0 * 4 + nt) * L] = (double)a.srd[0][nt];
-        pk[(8 + 1 * 4 + nt) * L] = (double)a.srd[1][nt];
-        pk[(16 + nt) * L] = (double)a.cnt[nt];
         // what the ordered fold needs of a shard: whether it has a qualifying record, its first AF, the max of the rest
         gm[nt * L] = a.gm_n[nt] > 0 ? a.gm_first_af[nt] : -1.0f;
         gm[(4 + nt) * L] = a.gm_n[nt] > 1 ? a.gm_rest[nt] : -INFINITY;
+    }
+    if (o.sl_fmt == AMPLI_SLICE_SLIM) {
+        const long long lim_d = (1ll << 26) / o.sl_n, lim_c = (1ll << 17) / o.sl_n; // this shard's share of a field
+        bool fits = (long long)a.nrec < lim_c;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            fits = fits && a.srd[0][nt] >= 0 && a.srd[0][nt] < lim_d && a.srd[1][nt] >= 0 && a.srd[1][nt] < lim_d && (long long)a.cnt[nt] < lim_c;
+            pk[(8 + nt) * L] = (double)a.srd[0][nt] + (double)a.srd[1][nt] * SLIM_D;
+        }
+        pk[12 * L] = (double)a.cnt[0] + (double)a.cnt[1] * SLIM_C + (double)a.cnt[2] * SLIM_C2;
+        pk[13 * L] = (double)a.cnt[3] + (double)a.nrec * SLIM_C;
+        if (!fits && o.sl_flags) atomicOr(o.sl_flags, AMPLI_FLAG_SLICE_RANGE);
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        pk[(8 + 0 * 4 + nt) * L] = (double)a.srd[0][nt];
+        pk[(8 + 1 * 4 + nt) * L] = (double)a.srd[1][nt];
+        pk[(16 + nt) * L] = (double)a.cnt[nt];
     }
     pk[20 * L] = (double)a.nrec;
 }
@@ -1200,7 +1230,7 @@ __device__ __forceinline__ FinOut slice_block_view(char *blk, const long long L)
 __global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double *__restrict__ sums, const float *__restrict__ gm,
                                                                    const size_t gm_stride /* elements between the shards' pairs */,
                                                                    const int nparts, const long long L, const long long p0,
-                                                                   const long long P, const float C, const int cov, char *blk)
+                                                                   const long long P, const float C, const int cov, char *blk, const int fmt)
 {
     // one thread per (nucleotide, position of the slice): the slice is short (P / n positions), so the launch is a
     // latency chain -- four times the threads, a quarter of the chain
@@ -1218,9 +1248,25 @@ __global__ __launch_bounds__(256) void error_finalize_slice_kernel(const double 
         else { if (rest <= fa) rest = fa; if (rest <= rr) rest = rr; n = 2; }
     }
     const FinOut o = slice_block_view(blk, L);
-    const bool bad = finalize_one(nt, sums[(0 * 4 + nt) * L + q], sums[(1 * 4 + nt) * L + q], (long long)sums[(8 + 0 * 4 + nt) * L + q],
-                                  (long long)sums[(8 + 1 * 4 + nt) * L + q], (int)sums[(16 + nt) * L + q], (int)sums[20 * L + q], n, rest,
-                                  L, q, envelope_limit(C, cov), o);
+    long long d_fw, d_bw;
+    int cnt, nrec;
+    if (fmt == AMPLI_SLICE_SLIM) { // the summed fields come apart again: every one stayed below its width (checked where the shards packed them)
+        const double d = sums[(8 + nt) * L + q], hi = floor(d / SLIM_D);
+        d_fw = (long long)(d - hi * SLIM_D);
+        d_bw = (long long)hi;
+        const double c0 = sums[12 * L + q], c1 = sums[13 * L + q];
+        const double c0_2 = floor(c0 / SLIM_C2), c0_r = c0 - c0_2 * SLIM_C2, c0_1 = floor(c0_r / SLIM_C), c0_0 = c0_r - c0_1 * SLIM_C;
+        const double c1_1 = floor(c1 / SLIM_C), c1_0 = c1 - c1_1 * SLIM_C;
+        cnt = (int)(nt == 0 ? c0_0 : nt == 1 ? c0_1 : nt == 2 ? c0_2 : c1_0);
+        nrec = (int)c1_1;
+    } else {
+        d_fw = (long long)sums[(8 + 0 * 4 + nt) * L + q];
+        d_bw = (long long)sums[(8 + 1 * 4 + nt) * L + q];
+        cnt = (int)sums[(16 + nt) * L + q];
+        nrec = (int)sums[20 * L + q];
+    }
+    const bool bad = finalize_one(nt, sums[(0 * 4 + nt) * L + q], sums[(1 * 4 + nt) * L + q], d_fw, d_bw, cnt, nrec, n, rest, L, q,
+                                  envelope_limit(C, cov), o);
     if (bad) atomicOr(o.flags, 1);
 }
 
@@ -2016,14 +2062,28 @@ extern "C" int64_t ampli_slice_len(int64_t P, int32_t n_slices)
     return (per + 63) / 64 * 64;
 }
 
-extern "C" int ampli_slice_bytes(int64_t P, int32_t n_slices, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes)
+extern "C" int32_t ampli_slice_planes(int32_t format) { return slice_planes(format); }
+
+extern "C" int ampli_set_slice_format(ampli_ctx *ctx, int32_t format)
+{
+    if (!ctx || (format != AMPLI_SLICE_WIDE && format != AMPLI_SLICE_SLIM)) return AMPLI_E_INVALID;
+    ctx->slice_fmt = format;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_slice_bytes_fmt(int64_t P, int32_t n_slices, int32_t format, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes)
 {
     const int64_t L = ampli_slice_len(P, n_slices);
-    if (L <= 0) return AMPLI_E_INVALID;
-    if (sums_bytes) *sums_bytes = (size_t)n_slices * 21 * (size_t)L * sizeof(double);
+    if (L <= 0 || (format != AMPLI_SLICE_WIDE && format != AMPLI_SLICE_SLIM)) return AMPLI_E_INVALID;
+    if (sums_bytes) *sums_bytes = (size_t)n_slices * (size_t)slice_planes(format) * (size_t)L * sizeof(double);
     if (gm_bytes) *gm_bytes = (size_t)n_slices * 8 * (size_t)L * sizeof(float);
     if (block_bytes) *block_bytes = slice_block_bytes(L);
     return AMPLI_OK;
+}
+
+extern "C" int ampli_slice_bytes(int64_t P, int32_t n_slices, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes)
+{
+    return ampli_slice_bytes_fmt(P, n_slices, AMPLI_SLICE_WIDE, sums_bytes, gm_bytes, block_bytes);
 }
 
 extern "C" int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
@@ -2035,7 +2095,8 @@ extern "C" int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, 
     FinOut fo = {};
     fo.slice_len = ampli_slice_len(P, n_slices);
     fo.sl_group = ctx->grp_size; // buffers [n_slices][group][planes][L]; this call fills batch grp_index
-    fo.sl_sums = d_sums + (size_t)ctx->grp_index * 21 * (size_t)fo.slice_len;
+    fo.sl_fmt = ctx->slice_fmt; fo.sl_n = n_slices; fo.sl_flags = ctx->d_flags;
+    fo.sl_sums = d_sums + (size_t)ctx->grp_index * slice_planes(fo.sl_fmt) * (size_t)fo.slice_len;
     fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
     return error_reduce_impl(ctx, dense_cohort(ctx, d_recs, P, E, S, d_dup_off, nullptr), P, first_sample, C, cov, nullptr, fo);
 }
@@ -2049,7 +2110,8 @@ extern "C" int ampli_acc_to_slices(ampli_ctx *ctx, const ampli_acc_table *d_acc,
     FinOut fo = {};
     fo.slice_len = ampli_slice_len(P, n_slices);
     fo.sl_group = ctx->grp_size;
-    fo.sl_sums = d_sums + (size_t)ctx->grp_index * 21 * (size_t)fo.slice_len;
+    fo.sl_fmt = ctx->slice_fmt; fo.sl_n = n_slices; fo.sl_flags = ctx->d_flags;
+    fo.sl_sums = d_sums + (size_t)ctx->grp_index * slice_planes(fo.sl_fmt) * (size_t)fo.slice_len;
     fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
     hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, fo);
     return check_launch(ctx, "acc_pack_sliced_kernel");
@@ -2063,10 +2125,10 @@ extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_s
         return fail(ctx, AMPLI_E_INVALID, "error_finalize_slice: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long L = ampli_slice_len(P, n_slices);
-    const size_t G = (size_t)ctx->grp_size, g = (size_t)ctx->grp_index; // [group][21][L] sums, [n][group][8][L] pairs, [group][block] out
+    const size_t G = (size_t)ctx->grp_size, g = (size_t)ctx->grp_index; // [group][planes][L] sums, [n][group][8][L] pairs, [group][block] out
     hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((4 * L + 255) / 256)), dim3(256), 0, ctx->stream,
-                       d_sum_slice + g * 21 * (size_t)L, d_gm_recv + g * 8 * (size_t)L, G * 8 * (size_t)L, (int)n_slices, L,
-                       (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block + g * slice_block_bytes(L));
+                       d_sum_slice + g * (size_t)slice_planes(ctx->slice_fmt) * (size_t)L, d_gm_recv + g * 8 * (size_t)L, G * 8 * (size_t)L, (int)n_slices, L,
+                       (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block + g * slice_block_bytes(L), ctx->slice_fmt);
     return check_launch(ctx, "error_finalize_slice_kernel");
 }
 

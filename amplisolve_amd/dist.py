@@ -120,15 +120,20 @@ class TableMerger:
         return acc
 
 
-def slice_geometry(P: int, world: int):
-    """(L, sums_bytes, gm_bytes, block_bytes) of the position-sliced exchange (ampli_slice_len / ampli_slice_bytes)."""
+def slice_geometry(P: int, world: int, slim: bool = False):
+    """(L, sums_bytes, gm_bytes, block_bytes) of the position-sliced exchange (ampli_slice_len / ampli_slice_bytes_fmt)."""
     from ._lib import hip_lib
 
     lib = hip_lib()
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
-    if lib.ampli_slice_bytes(P, world, C.byref(a), C.byref(b), C.byref(c)) != 0:
-        raise ValueError("ampli_slice_bytes failed")
+    if lib.ampli_slice_bytes_fmt(P, world, 1 if slim else 0, C.byref(a), C.byref(b), C.byref(c)) != 0:
+        raise ValueError("ampli_slice_bytes_fmt failed")
     return int(lib.ampli_slice_len(P, world)), a.value, b.value, c.value
+
+
+def slice_planes(slim: bool = False) -> int:
+    """doubles per position in the sums of the sliced exchange: 21 (wide) or 14 (slim: integer planes packed, include/amplisolve_hip.h)"""
+    return 14 if slim else 21
 
 
 class SlicedMerger:
@@ -136,36 +141,38 @@ class SlicedMerger:
 
     Rank k owns the positions [k*L, (k+1)*L).  Per batch:
 
-        error_reduce_sliced -> sums[slot] f64 [world][21][L], gm[slot] f32 [world][8][L]
-        start_exchange(slot):  reduce-scatter(SUM) sums -> sum_slice[slot] [21][L]
+        error_reduce_sliced -> sums[slot] f64 [world][planes][L] (planes = 21, or 14 in the slim format), gm[slot] f32 [world][8][L]
+        start_exchange(slot):  reduce-scatter(SUM) sums -> sum_slice[slot] [planes][L]
                                all-to-all gm           -> gm_recv[slot] [world][8][L]
         error_finalize_slice   -> block[slot]          (this rank's slice of the error table)
         start_gather(slot):    all-gather block        -> blocks[slot] [world][block_bytes]
         error_table_unslice    -> the plane-major error table on every rank
 
-    Received bytes per rank and batch at world = 8, P = 100 k: 14.7 + 2.8 + 7.7 = 25 MB, against 29.4 + 33.6 = 63 MB
-    for the all-reduce + all-gather of whole tables (TableMerger).  `depth` buffer sets let a caller keep that many
+    Received bytes per rank and batch at world = 8, P = 100 k: 14.7 + 2.8 + 7.7 = 25.3 MB (slim sums: 9.8 + 2.8 + 7.7 = 20.4 MB),
+    against 29.4 + 33.6 = 63 MB for the all-reduce + all-gather of whole tables (TableMerger).  `depth` buffer sets let a caller keep that many
     batches in flight; the collectives ride on RCCL's stream.  Backends without reduce-scatter / all-to-all on device
     tensors (gloo: rehearsals and CPU tests) get the same data movement out of all-reduce / all-gather.
     """
 
-    def __init__(self, P: int, world: int, rank: int, device, group=None, depth: int = 3, batches: int = 1):
+    def __init__(self, P: int, world: int, rank: int, device, group=None, depth: int = 3, batches: int = 1, slim: bool = False):
         """batches = G > 1: every buffer holds G independent batches per slice chunk (ampli_set_slice_group(ctx, G, g)
         selects the batch a kernel call addresses) and ONE round of collectives serves all of them -- fewer, larger
-        messages and a third of the cross-stream waits per batch."""
+        messages and a third of the cross-stream waits per batch.  slim: the sums travel as 14 packed planes instead of 21
+        (the contexts that fill / read these buffers must be in the same format: Context.set_slice_format)."""
         import torch
         import torch.distributed as dist
 
         self.P, self.world, self.rank, self.group, self.depth, self.batches = P, world, rank, group, depth, batches
-        self.L, sums_bytes, gm_bytes, self.block_bytes = slice_geometry(P, world)
+        self.slim, self.planes = bool(slim), slice_planes(slim)
+        self.L, sums_bytes, gm_bytes, self.block_bytes = slice_geometry(P, world, slim)
         L = self.L * batches  # every plane length below is per slice chunk = `batches` batches back to back
         sums_bytes, gm_bytes = sums_bytes * batches, gm_bytes * batches
         self.native = dist.get_backend(group) == "nccl"
         z = dict(device=device)
         # zeroed once: entries of the padding positions (>= P) are never written by the kernels
-        self.sums = [torch.zeros(world * 21 * L, dtype=torch.float64, **z) for _ in range(depth)]
+        self.sums = [torch.zeros(world * self.planes * L, dtype=torch.float64, **z) for _ in range(depth)]
         self.gm = [torch.zeros(world * 8 * L, dtype=torch.float32, **z) for _ in range(depth)]
-        self.sum_slice = [torch.zeros(21 * L, dtype=torch.float64, **z) for _ in range(depth)]
+        self.sum_slice = [torch.zeros(self.planes * L, dtype=torch.float64, **z) for _ in range(depth)]
         self.gm_recv = [torch.zeros(world * 8 * L, dtype=torch.float32, **z) for _ in range(depth)]
         self.block = [torch.zeros(batches * self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
         self.blocks = [torch.zeros(world * batches * self.block_bytes, dtype=torch.uint8, **z) for _ in range(depth)]
@@ -199,7 +206,7 @@ class SlicedMerger:
             return (h1, h2)
         # rehearsal form: all-reduce + own chunk; all-gather + own column
         dist.all_reduce(self.sums[slot], op=dist.ReduceOp.SUM, group=self.group)
-        self.sum_slice[slot].copy_(self.sums[slot][r * 21 * L:(r + 1) * 21 * L])
+        self.sum_slice[slot].copy_(self.sums[slot][r * self.planes * L:(r + 1) * self.planes * L])
         dist.all_gather_into_tensor(self._a2a_tmp, self.gm[slot], group=self.group)
         self.gm_recv[slot].view(w, 8 * L).copy_(self._a2a_tmp.view(w, w, 8 * L)[:, r, :])
         return ()
@@ -219,8 +226,9 @@ class SlicedMerger:
         """What one batch's exchange brings to a rank (the collectives are issued once per `batches` batches, so a round
         moves `batches` times this): every other rank's contribution to the own slice, every other rank's block."""
         w, L = self.world, self.L
-        rs, a2a, ag = (w - 1) * 21 * L * 8, (w - 1) * 8 * L * 4, (w - 1) * self.block_bytes
-        return {"reduce_scatter_f64": rs, "all_to_all_f32": a2a, "all_gather_u8": ag, "total": rs + a2a + ag}
+        rs, a2a, ag = (w - 1) * self.planes * L * 8, (w - 1) * 8 * L * 4, (w - 1) * self.block_bytes
+        return {"reduce_scatter_f64": rs, "all_to_all_f32": a2a, "all_gather_u8": ag, "total": rs + a2a + ag,
+                "sums_format": f"{'slim' if self.slim else 'wide'}: {self.planes} doubles per position"}
 
     def time_collectives(self, reps: int = 10) -> dict:
         """Each of the three collectives alone, `reps` rounds back to back on slot 0's buffers, nothing else on the device:

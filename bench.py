@@ -54,6 +54,7 @@ def parse_args():
                     help="default: c3 on one GPU (the configuration the metric's target is quoted on); with --gpus N > 1: c4, "
                          "BASELINE's 8-GPU job of 1024 normals + 1024 tumours split N ways (strong scaling).  c2 / c3 with N > 1: "
                          "every rank owns a shard of that size (weak scaling)")
+    ap.add_argument("--wide-sums", action="store_true", help="N > 1, sliced merge: exchange the sums as 21 plain planes (168 B per position) instead of the 14 packed ones (112 B)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end leg (ASEQ text on disk -> tables / calls through the command lines)")
     ap.add_argument("--sustained", type=int, default=2000, help="passes of the sustained-rate block after the timed region (0 = skip)")
     ap.add_argument("--cold-batches", type=int, default=3, help="N = 1: distinct resident batches the cold-HBM block rotates over after the timed region "
@@ -488,8 +489,12 @@ def main():
     sliced = multi and args.merge == "sliced"
     G = args.group if args.group > 0 else (4 if args.steps >= 16 else 2 if args.steps >= 8 else 1)  # batches per round of collectives
     merger = None
+    # sums of the sliced exchange: 14 packed planes (112 B per position) unless a shard's values do not fit their share of a
+    # packed field -- the kernels flag that (AMPLI_FLAG_SLICE_RANGE) in warm-up and every rank then switches to the 21 plain planes
+    slim = sliced and not args.wide_sums
     if multi:
-        merger = (SlicedMerger(P, world, rank, ctx.device, batches=G) if sliced else
+        ctx.set_slice_format(slim)
+        merger = (SlicedMerger(P, world, rank, ctx.device, batches=G, slim=slim) if sliced else
                   TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack))
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
@@ -661,6 +666,18 @@ def main():
             merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack)
     run_steps(args.warmup, False)
     fence()
+    if sliced and slim:
+        own = torch.tensor([1 if (ctx.flags(clear=False) & 8) else 0], dtype=torch.int32, device=ctx.device)
+        dist.all_reduce(own, op=dist.ReduceOp.MAX)
+        if int(own.item()):
+            if rank == 0:
+                print("slim exchange format: a shard's sums do not fit their share of a packed field -- every rank switches to the wide format", file=sys.stderr)
+            ctx.flags(clear=True)
+            slim = False
+            ctx.set_slice_format(False)
+            merger = SlicedMerger(P, world, rank, ctx.device, batches=G, slim=False)
+            run_steps(args.warmup, False)
+            fence()
 
     def materialise():
         """sliced merge: the plane-major table of the last finished batch (outside the per-batch work)"""
@@ -906,8 +923,8 @@ def main():
         acc_bytes = ctx.lib.ampli_acc_bytes(P)
         # algorithmic bytes of error_reduce per launch: the records + what it writes (the accumulator table,
         # or at N = 1 the finalised error table: rate 32 B + thr 32 B + code 4 B + germ 16+4 B per position)
-        # (N > 1, sliced merge: 21 doubles + 8 floats per position into the exchange buffers = 200 B)
-        red_bytes = rec_bytes * P * S + ((200 * P if sliced else acc_bytes) if multi else 88 * P)
+        # (N > 1, sliced merge: 21 -- or 14, slim format -- doubles + 8 floats per position into the exchange buffers = 200 / 144 B)
+        red_bytes = rec_bytes * P * S + (((8 * merger.planes + 32) * P if sliced else acc_bytes) if multi else 88 * P)
         call_bytes = rec_bytes * P * T + 33 * P + P * T    # poisson_call: records + thresholds/ref + mask
         lay = {"i32": 0, "u16": 1, "u24": 2}[layout]
         if t_red >= t_call:

@@ -273,6 +273,19 @@ int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const double *d_packe
 int ampli_set_slice_group(ampli_ctx *ctx, int32_t group_size, int32_t group_index);
 int64_t ampli_slice_len(int64_t P, int32_t n_slices);
 int ampli_slice_bytes(int64_t P, int32_t n_slices, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes);
+/* The sums' format (round 4).  AMPLI_SLICE_WIDE (default): the 21 planes above, 168 B per position.  AMPLI_SLICE_SLIM: 14 planes,
+ * 112 B per position, the same ONE reduce-scatter of doubles: snt 8 | srd 4 (the two strands' depth sums of a nucleotide in one
+ * double: forward + reverse * 2^26) | cnt0 + cnt1 * 2^17 + cnt2 * 2^34 | cnt3 + nrec * 2^17.  Adding doubles adds the fields
+ * independently and exactly while every field's total stays below its width, so each of the n shards may use 1/n of a field's
+ * range (depth sums < 2^26 / n, counts < 2^17 / n per position): ampli_error_reduce_sliced / ampli_acc_to_slices check that where
+ * they pack and raise AMPLI_FLAG_SLICE_RANGE otherwise -- repeat the exchange in the wide format then.  The format applies to
+ * every sliced entry point of the context (the [21] in the shapes above becomes ampli_slice_planes(format)); results are
+ * bit-identical in both. */
+#define AMPLI_SLICE_WIDE 0
+#define AMPLI_SLICE_SLIM 1
+int ampli_set_slice_format(ampli_ctx *ctx, int32_t format);
+int32_t ampli_slice_planes(int32_t format);
+int ampli_slice_bytes_fmt(int64_t P, int32_t n_slices, int32_t format, size_t *sums_bytes, size_t *gm_bytes, size_t *block_bytes);
 int ampli_error_reduce_sliced(ampli_ctx *ctx, const int32_t *d_recs, int64_t P, int64_t E, const uint32_t *d_dup_off,
                               int32_t S, int32_t first_sample, float C, int32_t coverage_cutoff, int32_t n_slices,
                               double *d_sums, float *d_gm);
@@ -458,6 +471,8 @@ int ampli_set_queue_items(ampli_ctx *ctx, int64_t items);
 /* Flags raised by kernels of this context since the last clear (synchronises the stream). */
 #define AMPLI_FLAG_QUEUE_OVERFLOW 4 /* poisson_call (prefilter) ran out of queue space: masks/calls incomplete, raise
                                        ampli_set_queue_items (or use AMPLI_POISSON_FULL) and rerun */
+#define AMPLI_FLAG_SLICE_RANGE 8 /* sliced exchange in the slim format: a shard's value does not fit its share of a packed field; repeat
+                                  * the exchange with ampli_set_slice_format(ctx, AMPLI_SLICE_WIDE) */
 #define AMPLI_FLAG_RERUN_GENERAL 2 /* error_reduce met a depth >= 2^22: its table is invalid, rerun with reduce_general = 1 */
 int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear);
 

@@ -91,13 +91,19 @@ def worker(rank, world, port, q):
 
 
 # ---- position-sliced merge: numpy twins of the three kernels around SlicedMerger's collectives ----
-def host_pack_sliced(part, P, world, L, sums, gm):
-    """twin of lane_acc_store_sliced (csrc/ampli_kernels.hip): partial table -> slice-major exchange buffers."""
-    planes = np.concatenate([part["snt"].reshape(8, P), part["srd"].reshape(8, P).astype(np.float64),
-                             part["cnt"].astype(np.float64), part["nrec"].reshape(1, P).astype(np.float64)])
+def host_pack_sliced(part, P, world, L, sums, gm, slim=False):
+    """twin of lane_acc_store_sliced (csrc/ampli_kernels.hip): partial table -> slice-major exchange buffers.
+    slim: 14 planes -- the two strands' depth sums of a nucleotide as lo + hi * 2^26, the counts three to a double in base 2^17"""
+    srd, cnt, nrec = part["srd"].astype(np.float64), part["cnt"].astype(np.float64), part["nrec"].astype(np.float64)
+    if slim:
+        assert (part["srd"] < (1 << 26) // world).all() and (part["cnt"] < (1 << 17) // world).all() and (part["nrec"] < (1 << 17) // world).all()
+        planes = np.concatenate([part["snt"].reshape(8, P), srd[0] + srd[1] * 2.0 ** 26,
+                                 (cnt[0] + cnt[1] * 2.0 ** 17 + cnt[2] * 2.0 ** 34).reshape(1, P), (cnt[3] + nrec * 2.0 ** 17).reshape(1, P)])
+    else:
+        planes = np.concatenate([part["snt"].reshape(8, P), srd.reshape(8, P), cnt, nrec.reshape(1, P)])
     pair = np.concatenate([np.where(part["gm_n"] > 0, part["gm_first_af"], np.float32(-1)),
                            np.where(part["gm_n"] > 1, part["gm_rest"], np.float32(-np.inf))]).astype(np.float32)
-    s, g = sums.numpy().reshape(world, 21, L), gm.numpy().reshape(world, 8, L)
+    s, g = sums.numpy().reshape(world, 14 if slim else 21, L), gm.numpy().reshape(world, 8, L)
     for k in range(world):
         lo, hi = k * L, min(P, (k + 1) * L)
         if hi > lo:
@@ -105,9 +111,16 @@ def host_pack_sliced(part, P, world, L, sums, gm):
             g[k, :, : hi - lo] = pair[:, lo:hi]
 
 
-def host_finalize_slice(sum_slice, gm_recv, world, L, n_valid):
+def host_finalize_slice(sum_slice, gm_recv, world, L, n_valid, slim=False):
     """twin of error_finalize_slice_kernel: ordered fold of the shards' germ-max pairs + the oracle's finalize."""
-    s, g = sum_slice.numpy().reshape(21, L)[:, :n_valid], gm_recv.numpy().reshape(world, 8, L)[:, :, :n_valid]
+    s, g = sum_slice.numpy().reshape(14 if slim else 21, L)[:, :n_valid], gm_recv.numpy().reshape(world, 8, L)[:, :, :n_valid]
+    if slim:  # the summed fields come apart again
+        hi = np.floor(s[8:12] / 2.0 ** 26)
+        c2 = np.floor(s[12] / 2.0 ** 34)
+        r = s[12] - c2 * 2.0 ** 34
+        c1 = np.floor(r / 2.0 ** 17)
+        n1 = np.floor(s[13] / 2.0 ** 17)
+        s = np.concatenate([s[:8], s[8:12] - hi * 2.0 ** 26, hi, np.stack([r - c1 * 2.0 ** 17, c1, c2, s[13] - n1 * 2.0 ** 17]), n1.reshape(1, -1)])
     n = np.zeros((4, n_valid), np.int32)
     rest = np.full((4, n_valid), -np.inf, np.float32)
     for k in range(world):
@@ -125,24 +138,25 @@ def host_finalize_slice(sum_slice, gm_recv, world, L, n_valid):
     return orc.error_finalize(acc)
 
 
-def sliced_worker(rank, world, port, q):
+def sliced_worker(rank, world, port, q, slim=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        L, _, _, block_bytes = slice_geometry(P, world)
-        merger = SlicedMerger(P, world, rank, "cpu")
+        L, _, _, block_bytes = slice_geometry(P, world, slim)
+        merger = SlicedMerger(P, world, rank, "cpu", slim=slim)
+        assert merger.planes == (14 if slim else 21) and merger.bytes_received_per_step()["reduce_scatter_f64"] == (world - 1) * merger.planes * L * 8
         lo, hi = shard_range(S, rank, world)
         n_valid = max(0, min(P, (rank + 1) * L) - rank * L)
         ok = True
         batches = []
         for b in range(3):  # three batches in flight, as bench.py keeps them
             rb = synth_recs(P, S, seed=4321 + b)
-            host_pack_sliced(orc.error_reduce(rb[lo:hi], P, 0.002, 100, first_sample=lo), P, world, L, merger.sums[b], merger.gm[b])
+            host_pack_sliced(orc.error_reduce(rb[lo:hi], P, 0.002, 100, first_sample=lo), P, world, L, merger.sums[b], merger.gm[b], slim)
             batches.append((rb, merger.start_exchange(b)))
         gathers = []
         for b, (rb, h) in enumerate(batches):
             merger.wait(h)
-            fin = host_finalize_slice(merger.sum_slice[b], merger.gm_recv[b], world, L, n_valid)
+            fin = host_finalize_slice(merger.sum_slice[b], merger.gm_recv[b], world, L, n_valid, slim)
             # block = this rank's slice of the table, serialised (here: rate | thr | code | germ_present | germ_val as f64)
             blob = np.concatenate([fin["rate"].reshape(-1).view(np.uint8), fin["thr"].reshape(-1).view(np.uint8), fin["code"].reshape(-1),
                                    fin["germ_present"].reshape(-1), fin["germ_val"].reshape(-1).view(np.uint8)])
@@ -178,17 +192,19 @@ def sliced_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("slim", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_sliced_merge_protocol_over_gloo(world):
+def test_sliced_merge_protocol_over_gloo(world, slim):
     """Slice ownership, chunk order of the reduce-scatter / all-to-all / all-gather and the ordered germ-max fold:
-    every rank ends with every slice of the single-pass error table, bit for bit."""
+    every rank ends with every slice of the single-pass error table, bit for bit -- with the sums as 21 plain planes and as the
+    14 packed planes of the slim format (the fields of a packed double add up independently; round 4)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=sliced_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=sliced_worker, args=(r, world, port, q, slim)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

@@ -181,34 +181,43 @@ def test_shard_merge_matches_single_pass(ctx):
     assert_acc_equal(dst, full, skip=("gm_first",))  # the sample index is not part of the exchanged region
 
 
-def _sliced_merge_emulated(ctx, shards, P, firsts, E=0, dup_off=None, C_value=0.002, cov=100):
-    """The position-sliced merge (SlicedMerger's data movement) with the collectives replaced by tensor ops."""
+def _sliced_merge_emulated(ctx, shards, P, firsts, E=0, dup_off=None, C_value=0.002, cov=100, slim=False):
+    """The position-sliced merge (SlicedMerger's data movement) with the collectives replaced by tensor ops.
+    slim: the sums travel as 14 packed planes (AMPLI_SLICE_SLIM) instead of 21."""
     import torch
 
-    from amplisolve_amd.dist import slice_geometry
+    from amplisolve_amd.dist import slice_geometry, slice_planes
 
     n = len(shards)
-    L, _, _, block_bytes = slice_geometry(P, n)
-    sums, gms = [], []
-    for recs, first in zip(shards, firsts):
-        s = torch.zeros(n * 21 * L, dtype=torch.float64, device="cuda")
-        g = torch.zeros(n * 8 * L, dtype=torch.float32, device="cuda")
-        ctx.error_reduce_sliced(recs, P, n, s, g, C_value, cov, E=E, dup_off=dup_off, first_sample=first)
-        sums.append(s)
-        gms.append(g)
-    total = torch.stack(sums).sum(0).view(n, 21 * L)                      # reduce-scatter: rank k keeps row k
-    blocks = torch.zeros(n * block_bytes, dtype=torch.uint8, device="cuda")
-    for k in range(n):
-        recv = torch.stack([g.view(n, 8 * L)[k] for g in gms]).contiguous()  # all-to-all: chunk j = rank j's pair for slice k
-        ctx.error_finalize_slice(P, n, k, total[k].contiguous(), recv, blocks[k * block_bytes:(k + 1) * block_bytes], C_value, cov)
-    fin = ctx.error_table_unslice(P, n, blocks)                          # all-gather: the blocks back to back
+    L, sums_bytes, _, block_bytes = slice_geometry(P, n, slim)
+    pl = slice_planes(slim)
+    assert sums_bytes == n * pl * L * 8
+    ctx.set_slice_format(slim)
+    try:
+        sums, gms = [], []
+        for recs, first in zip(shards, firsts):
+            s = torch.zeros(n * pl * L, dtype=torch.float64, device="cuda")
+            g = torch.zeros(n * 8 * L, dtype=torch.float32, device="cuda")
+            ctx.error_reduce_sliced(recs, P, n, s, g, C_value, cov, E=E, dup_off=dup_off, first_sample=first)
+            sums.append(s)
+            gms.append(g)
+        total = torch.stack(sums).sum(0).view(n, pl * L)                      # reduce-scatter: rank k keeps row k
+        blocks = torch.zeros(n * block_bytes, dtype=torch.uint8, device="cuda")
+        for k in range(n):
+            recv = torch.stack([g.view(n, 8 * L)[k] for g in gms]).contiguous()  # all-to-all: chunk j = rank j's pair for slice k
+            ctx.error_finalize_slice(P, n, k, total[k].contiguous(), recv, blocks[k * block_bytes:(k + 1) * block_bytes], C_value, cov)
+        fin = ctx.error_table_unslice(P, n, blocks)                          # all-gather: the blocks back to back
+    finally:
+        ctx.set_slice_format(False)
     fin.blocks = blocks
     return fin
 
 
+@pytest.mark.parametrize("slim", [False, True])
 @pytest.mark.parametrize("P,S,n", [(2000, 48, 2), (1000, 37, 3), (4097, 64, 8), (100, 16, 8), (15, 300, 2), (777, 130, 4)])
-def test_sliced_merge_matches_single_pass(ctx, P, S, n):
-    """Reduce-scatter / all-to-all / all-gather merge of n sample shards == one pass over all samples."""
+def test_sliced_merge_matches_single_pass(ctx, P, S, n, slim):
+    """Reduce-scatter / all-to-all / all-gather merge of n sample shards == one pass over all samples, in both formats of the
+    sums (21 plain planes; 14 planes with the integer planes packed, round 4)."""
     from amplisolve_amd.dist import shard_range
 
     recs = synth_recs(P, S)
@@ -218,7 +227,9 @@ def test_sliced_merge_matches_single_pass(ctx, P, S, n):
     firsts = [a for a, b in cuts if b > a]
     if len(shards) < n:  # fewer samples than ranks cannot happen with shard_range here, but keep the emulation honest
         pytest.skip("empty shard")
-    fin = _sliced_merge_emulated(ctx, shards, P, firsts)
+    ctx.flags()
+    fin = _sliced_merge_emulated(ctx, shards, P, firsts, slim=slim)
+    assert ctx.flags() == 0  # no AMPLI_FLAG_SLICE_RANGE: every shard's values fit their share of the packed fields
     assert_final_equal(fin, ref)
     assert int(fin.flags.item()) == 0
     one = ctx.error_estimate(_t(recs), P)
@@ -248,26 +259,29 @@ def test_poisson_call_reads_thresholds_from_the_gathered_blocks(ctx, P, n):
         assert ctx.read_calls(a).tobytes() == ctx.read_calls(b).tobytes()
 
 
-def test_sliced_merge_with_groups_of_batches(ctx):
+@pytest.mark.parametrize("slim", [False, True])
+def test_sliced_merge_with_groups_of_batches(ctx, slim):
     """ampli_set_slice_group: G independent batches share one round of collectives (buffers [n][G][planes][L]); every
     batch of the group comes out as its own single pass, and poisson_call reads the right batch's blocks."""
     import torch
 
     from amplisolve_amd.api import POISSON_PREFILTER
-    from amplisolve_amd.dist import shard_range, slice_geometry
+    from amplisolve_amd.dist import shard_range, slice_geometry, slice_planes
 
     P, S, n, G, T = 1000, 24, 3, 2, 4
-    L, _, _, bb = slice_geometry(P, n)
+    L, _, _, bb = slice_geometry(P, n, slim)
+    pl = slice_planes(slim)
     batches = [synth_recs(P, S, seed=900 + g) for g in range(G)]
     cuts = [shard_range(S, r, n) for r in range(n)]
-    sums = [torch.zeros(n * G * 21 * L, dtype=torch.float64, device="cuda") for _ in range(n)]
+    sums = [torch.zeros(n * G * pl * L, dtype=torch.float64, device="cuda") for _ in range(n)]
     gms = [torch.zeros(n * G * 8 * L, dtype=torch.float32, device="cuda") for _ in range(n)]
+    ctx.set_slice_format(slim)
     try:
         for r, (a, b) in enumerate(cuts):
             for g in range(G):
                 ctx.set_slice_group(G, g)
                 ctx.error_reduce_sliced(_t(batches[g][a:b]), P, n, sums[r], gms[r], first_sample=a)
-        total = torch.stack(sums).sum(0).view(n, G * 21 * L)                       # reduce-scatter: rank k keeps chunk k
+        total = torch.stack(sums).sum(0).view(n, G * pl * L)                       # reduce-scatter: rank k keeps chunk k
         block = [torch.zeros(G * bb, dtype=torch.uint8, device="cuda") for _ in range(n)]
         for k in range(n):
             recv = torch.stack([gm.view(n, G * 8 * L)[k] for gm in gms]).contiguous()  # all-to-all
@@ -286,6 +300,7 @@ def test_sliced_merge_with_groups_of_batches(ctx):
             assert torch.equal(a["call_mask"], b["call_mask"])
     finally:
         ctx.set_slice_group(1, 0)
+        ctx.set_slice_format(False)
 
 
 def test_sliced_merge_edge_cases_and_extras(ctx):
@@ -308,8 +323,28 @@ def test_sliced_merge_edge_cases_and_extras(ctx):
         for general in (False, True):
             ctx.set_tuning(0, general=general)
             fin = _sliced_merge_emulated(ctx, [_t(recs[a:b]) for a, b in cuts], P, [a for a, _ in cuts], E=E, dup_off=_t(dup_off))
+            slim = _sliced_merge_emulated(ctx, [_t(recs[a:b]) for a, b in cuts], P, [a for a, _ in cuts], E=E, dup_off=_t(dup_off), slim=True)
             ctx.set_tuning(0)
             assert_final_equal(fin, ref)
+            assert_final_equal(slim, ref)
+
+
+def test_slim_exchange_format_flags_values_beyond_a_shards_share_of_a_field(ctx):
+    """AMPLI_SLICE_SLIM packs the two strands' depth sums of a nucleotide into one double (2^26 each) and the record counts three
+    to a double (2^17 each); with n shards each may use 1/n of a field.  A shard beyond its share raises AMPLI_FLAG_SLICE_RANGE
+    (the caller repeats the exchange in the wide format, which has no such limit and gives the single-pass table)."""
+    P, S, n = 128, 40, 8
+    recs = synth_recs(P, S)
+    recs[:, 7] = [300_000, 10, 5, 3, 290_000, 8, 4, 2]  # a shard of 33 such records: depth sums of 33 x 3e5 = 9.9e6 > 2^26 / 8
+    ref = orc.error_finalize(orc.error_reduce(recs, P))
+    ctx.flags()
+    parts = [recs[:33]] + [recs[33 + i:34 + i] for i in range(7)]  # n = 8 shards, seven of them one sample
+    starts = [0] + [33 + i for i in range(7)]
+    fin = _sliced_merge_emulated(ctx, [_t(x) for x in parts], P, starts, slim=True)
+    assert ctx.flags() & 8  # AMPLI_FLAG_SLICE_RANGE
+    fin = _sliced_merge_emulated(ctx, [_t(x) for x in parts], P, starts, slim=False)
+    assert ctx.flags() == 0
+    assert_final_equal(fin, ref)
 
 
 def test_sliced_merge_reports_the_exactness_flag(ctx):
