@@ -681,8 +681,10 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
     }
     const int64_t P = panel.P();
     const int S = (int)im->files.size();
-    // samples per chunk: about chunk_bytes of records in the narrowest layout allowed, at least one sample, and not so few
-    // that the parser threads idle
+    // samples per chunk: about chunk_bytes of records IN THE NARROWEST LAYOUT ALLOWED, at least one sample, and not so few
+    // that the parser threads idle.  A chunk whose counts need wider records keeps its sample count, so AMPLISOLVE_CHUNK_MB = 128
+    // means up to 192 MB (24-bit fields) or 256 MB (int32) for such a chunk, in each of the ring's slots and of the device's;
+    // the slot is re-allocated (plain memory; pinned again on its next upload) by the producer, off the consumer's path
     int per = (int)std::max<int64_t>(1, (int64_t)(chunk_bytes / (size_t)std::max<int64_t>(1, P * (int64_t)record_bytes(im->start_layout))));
     per = std::max(per, std::min(S, im->n_threads));
     per = std::min(per, std::max(1, S));
@@ -709,6 +711,20 @@ void ChunkStream::shutdown()
     }
     im->cv.notify_all();
     if (im->producer.joinable()) im->producer.join();
+    im->slots.clear();
+}
+
+void ChunkStream::abandon()
+{
+    {
+        std::lock_guard<std::mutex> lk(im->mu);
+        im->stop = true;
+    }
+    im->cv.notify_all();
+    if (im->producer.joinable()) im->producer.join();
+    for (auto &c : im->slots) { // the buffers stay mapped (and pinned) until the process ends
+        if (c) { c->prim = nullptr; c->ext = nullptr; c->prim_pinned = c->ext_pinned = false; }
+    }
     im->slots.clear();
 }
 

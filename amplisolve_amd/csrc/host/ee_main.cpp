@@ -41,6 +41,7 @@ int main(int argc, char **argv)
     a.output_dir = token(argv[7], "output_dir");
     if (const char *e = getenv("AMPLISOLVE_REFBASES_FILE")) a.refbases_file = e; // pre-computed chrom/pos/base table instead of the FASTA
     a.native = ampli::native_dist_from_env(a.output_dir); // AMPLISOLVE_WORLD_SIZE > 1: one shard of a one-process-per-GPU run (RCCL)
+    a.process_ends = !(getenv("AMPLISOLVE_EXIT") && std::string(getenv("AMPLISOLVE_EXIT")) == "orderly"); // finish_process() leaves with _exit
     const int rc = ampli::run_error_estimation(a);
     if (getenv("AMPLISOLVE_TIMING")) ampli::PhaseClock::report(std::cerr, ampli::PhaseClock::now() - t_main);
     const int status = (strict || a.native.world > 1) ? (rc ? 1 : 0) : 0; // a failed shard must be visible to whatever launched the shards

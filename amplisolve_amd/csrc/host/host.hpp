@@ -121,6 +121,8 @@ public:
     Chunk *next();            // next chunk in order, nullptr after the last; rethrows the producer's Error
     void release(Chunk *c);   // the chunk's buffers may be refilled
     void shutdown();          // stop the producer and free the ring now (the destructor does the same)
+    void abandon();           // stop the producer and LEAVE the ring's buffers to the end of the process (a command line about to exit:
+                              //  unpinning and unmapping half a gigabyte beside the writers costs them more than the exit does)
     int samples_per_chunk() const;
     int chunks() const;
     double parse_seconds() const; // producer time spent parsing so far
@@ -185,11 +187,13 @@ struct EeArgs {
     std::string refbases_file; // test hook: skip the FASTA, read chrom/pos/base lines
     const ampli_host_shard *shard = nullptr; // one shard of a multi-process run (include/amplisolve_host.h)
     NativeDist native;                       // or: one shard with the library's own RCCL transport (shard == nullptr)
+    bool process_ends = false;               // the caller is an executable that exits right after: big buffers are left to the exit
 };
 struct VcArgs {
     std::string error_file, tumour_dir, output_dir, coverage_cutoff = "100", p_value = "0.05";
     const ampli_host_shard *shard = nullptr;
     NativeDist native;
+    bool process_ends = false;
 };
 // computeCounts (bam.cpp): one BAM file -> <out_dir>/<name>.PILEUP.ASEQ
 struct CcArgs {

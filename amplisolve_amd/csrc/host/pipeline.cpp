@@ -254,6 +254,16 @@ struct Background {
     }
 };
 
+// The ring is up to 512 MB of touched, pinned memory.  Freeing it on a background thread takes ~35 ms during which the address
+// space is write-locked again and again: the table writer / the annotation threads beside it stall in their own page faults
+// (write_table 8 -> 30 ms on config 3).  An executable that is about to _exit leaves the buffers to the exit instead
+// (AMPLISOLVE_RING_TEARDOWN=background restores the freeing, for comparison).
+bool leave_ring_to_exit(const bool process_ends)
+{
+    if (const char *e = getenv("AMPLISOLVE_RING_TEARDOWN")) return std::string(e) == "exit";
+    return process_ends;
+}
+
 size_t chunk_bytes_setting()
 {
     // about this many bytes of records (in the narrowest layout) per chunk (AMPLISOLVE_CHUNK_MB); three chunks are in flight
@@ -637,11 +647,16 @@ int run_error_estimation(const EeArgs &a)
                 }
                 parse_s += cs.parse_seconds();
                 PhaseClock::add("parser_busy", cs.parse_seconds(), false);
-                ChunkStream *done_stream = own.release(); // unpinning + unmapping the ring: beside the download and the table writer
-                ring_teardown.run([done_stream] {
-                    PhaseClock::Scope sc2("stream_teardown", false);
+                ChunkStream *done_stream = own.release();
+                if (leave_ring_to_exit(a.process_ends)) {
+                    done_stream->abandon();
                     delete done_stream;
-                });
+                } else { // a library caller lives on: unpin + unmap the ring, beside the download and the table writer
+                    ring_teardown.run([done_stream] {
+                        PhaseClock::Scope sc2("stream_teardown", false);
+                        delete done_stream;
+                    });
+                }
             }
             int32_t kflags = 0;
             {
@@ -898,11 +913,16 @@ int run_variant_calling(const VcArgs &a)
             }
             parse_s = cs.parse_seconds();
             PhaseClock::add("parser_busy", parse_s, false);
-            ChunkStream *done_stream = own.release(); // unpinning + unmapping the ring: beside the annotation and the writers
-            ring_teardown.run([done_stream] {
-                PhaseClock::Scope sc2("stream_teardown", false);
+            ChunkStream *done_stream = own.release();
+            if (leave_ring_to_exit(a.process_ends)) {
+                done_stream->abandon();
                 delete done_stream;
-            });
+            } else { // a library caller lives on: unpin + unmap the ring, beside the annotation and the writers
+                ring_teardown.run([done_stream] {
+                    PhaseClock::Scope sc2("stream_teardown", false);
+                    delete done_stream;
+                });
+            }
         }
         const double t2 = now_s();
         // Calls within rounding of a gate.  The device forms Q in fp64 with ROCm's exp / log, the reference with glibc and an

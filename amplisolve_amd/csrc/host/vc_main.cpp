@@ -36,6 +36,7 @@ int main(int argc, char **argv)
     a.coverage_cutoff = token(argv[4], "coverage_cutoff");
     a.p_value = token(argv[5], "p_value");
     a.native = ampli::native_dist_from_env(a.output_dir); // AMPLISOLVE_WORLD_SIZE > 1: one shard of a one-process-per-GPU run (RCCL)
+    a.process_ends = !(getenv("AMPLISOLVE_EXIT") && std::string(getenv("AMPLISOLVE_EXIT")) == "orderly"); // finish_process() leaves with _exit
     const int rc = ampli::run_variant_calling(a);
     if (getenv("AMPLISOLVE_TIMING")) ampli::PhaseClock::report(std::cerr, ampli::PhaseClock::now() - t_main);
     const int status = (strict || a.native.world > 1) ? (rc ? 1 : 0) : 0; // a failed shard must be visible to whatever launched the shards

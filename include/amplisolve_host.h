@@ -151,7 +151,10 @@ int ampli_host_run_variant_calling_sharded(const char *error_file, const char *t
  * kept, bases counted, lines written. */
 int ampli_host_compute_counts(const char *vcf, const char *bam, const char *out_dir, int32_t threads, int32_t mbq, int32_t mrq, int32_t mdc,
                               int64_t *stats);
-/* the container only (no GPU): stats[4] = alignment records, uncompressed bytes, reference sequences, malformed records */
+/* the container only (no GPU): stats[4] = alignment records, uncompressed bytes, reference sequences, malformed records (complete
+ * records whose CIGAR does not add up to their l_seq or whose fields overrun their block: counted and skipped).  Bytes behind the
+ * last complete record -- a truncated or desynchronised stream -- are an error (AMPLI_E_INVALID), not a count: since round 3 the call
+ * fails instead of reporting them in stats[3]. */
 int ampli_host_bam_scan(const char *bam, int32_t threads, int64_t *stats);
 
 /* the decision guard of the variant-calling command line for calls within 1e-6 of a gate (AMPLI_CALL_BORDERLINE): Q by the
