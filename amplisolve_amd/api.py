@@ -192,6 +192,10 @@ class Context:
     def wait_calls(self):
         self._check(self.lib.ampli_wait_calls(self.h))
 
+    def set_reduce_compact(self, on: bool):
+        """error_estimate on uint16 records through the compact-state kernel (five waves per SIMD) where its shape applies; same results"""
+        self._check(self.lib.ampli_set_reduce_compact(self.h, int(bool(on))))
+
     def set_slice_format(self, slim: bool):
         """sums of the sliced exchange as 14 packed planes (slim) or 21 plain ones (ampli_set_slice_format)"""
         self._check(self.lib.ampli_set_slice_format(self.h, 1 if slim else 0))

@@ -297,6 +297,13 @@ extern "C" int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, in
     return AMPLI_OK;
 }
 
+extern "C" int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    ctx->reduce_compact = on ? 1 : 0;
+    return AMPLI_OK;
+}
+
 extern "C" int ampli_set_poisson_tuning(ampli_ctx *ctx, int32_t rows_per_wave, int32_t drain_blocks_per_shard)
 {
     if (!ctx || rows_per_wave < 0 || drain_blocks_per_shard < 0 || drain_blocks_per_shard > 65535) return AMPLI_E_INVALID;
@@ -1058,6 +1065,208 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
             // fused epilogue (single split only): the merged state is in registers, finalize it here and spare the
             // table round trip through HBM plus a launch
             if (fin.rate) finalize_lane(a, P, p_raw, C, cov, fin);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// error_reduce for uint16 records with a COMPACT per-position state (round 4): the same one-wave-per-position loop as
+// error_reduce_kernel<true, 1, AMPLI_RECORDS_U16>, in fewer registers, so that FIVE waves fit a SIMD instead of four.
+// What the shipped kernel's 120 VGPRs are (code objects, round 4): the loop needs 110, the LaneAcc-by-LaneAcc merge of the
+// epilogue the rest.  Here:
+//   * strand-depth sums in 32 bits (a uint16 record's strand depth is < 2^18, a lane takes at most 8191 records);
+//   * the four qualifying counts as two registers of 16-bit halves (a lane takes at most 8191 records);
+//   * the first qualifying record of the Germ_Max state machine kept as its AF (one float, formed in the rare block where a
+//     lane meets it) instead of the fraction x / RD (two registers); its sample index is not kept at all (bookkeeping of the
+//     accumulator table, which this kernel does not write);
+//   * nrec and the "depth beyond the fast envelope" bit share a register;
+//   * the epilogue combines the four chunks field by field through LDS and finalises nucleotide by nucleotide.
+// Only the headline's shape, like every specialisation here: fast arithmetic, one lane group, one sample split, no position
+// listed twice, finalize fused, no accumulator table; everything else takes error_reduce_kernel.  Same results, bit for bit.
+// ---------------------------------------------------------------------------
+struct Fast16 {
+    int sx[2][4];
+    int sd[2][4];
+    double sp[2][4];
+    unsigned cnt01, cnt23; // cnt[0] | cnt[1] << 16, cnt[2] | cnt[3] << 16
+    int gn[4];
+    float gfa[4];          // AF of the first qualifying record (EE:1229-1232); its value is dropped by the reference (EE:1258-1261)
+    int gbx[4], gbd[4];    // best later record as a fraction (0/1 until one exists)
+    unsigned nrec_bad;     // nrec | bad << 31
+    unsigned long long zmask[4];
+};
+
+__device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1, const float C, const int cov)
+{
+    const bool present = r0.x != AMPLI_ABSENT;
+    const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
+    const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
+    const int FW = fw[0] + fw[1] + fw[2] + fw[3];  // EE:1175
+    const int BW = bw[0] + bw[1] + bw[2] + bw[3];  // EE:1176
+    const int RD = FW + BW;
+    const bool covok = present && FW >= cov && BW >= cov; // EE:1595, EE:1251
+    a.nrec_bad += present ? 1u : 0u;               // EE:1659
+    if (!__any(covok)) return;
+    // RD < 2^19 for uint16 records: never beyond FAST_COUNT_LIMIT; the bit stays for the records-per-lane check
+    const int lim_fw = ampli_af_limit(FW), lim_bw = ampli_af_limit(BW), lim_rd = ampli_af_limit(RD);
+    const double prod_fw = (double)((float)FW * C); // EE:1597
+    const double prod_bw = (double)((float)BW * C); // EE:1599
+    const unsigned long long covmask = __builtin_amdgcn_ballot_w64(covok);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
+            a.sx[0][nt] += fw[nt]; a.sd[0][nt] += FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
+            a.sx[1][nt] += bw[nt]; a.sd[1][nt] += BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
+            if (nt < 2) a.cnt01 += nt == 0 ? 1u : 65536u;                     // EE:1606
+            else a.cnt23 += nt == 2 ? 1u : 65536u;
+        }
+        const int x = fw[nt] + bw[nt];
+        const bool pass = covok && x <= lim_rd; // EE:1251: float(X)/float(RD) <= 0.05
+        bool cand = pass;
+        if ((__builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask) & a.zmask[nt]) {
+            const bool is_first = pass && a.gn[nt] == 0;
+            if (is_first) { a.gfa[nt] = (float)x / (float)RD; a.gn[nt] = 1; } // EE:1229-1232
+            a.zmask[nt] = __builtin_amdgcn_ballot_w64(a.gn[nt] == 0);
+            cand = pass && !is_first;
+        }
+        const bool better = cand && mul24x24(x, a.gbd[nt]) > mul24x24(a.gbx[nt], RD); // EE:1266, ties keep the value
+        a.gbx[nt] = better ? x : a.gbx[nt];
+        a.gbd[nt] = better ? RD : a.gbd[nt];
+        a.gn[nt] += cand ? 1 : 0;
+    }
+}
+
+struct Red16Shared {
+    double snt[2][8][64];
+    long long srd[2][8][64];
+    int ints[2][9][64];   // cnt[4] | nrec | gm_n[4]
+    float flts[2][8][64]; // first_af[4] | rest[4]
+};
+
+// one chunk's summary, in the units the chunks are combined in
+struct Part16 {
+    double snt[2][4];
+    long long srd[2][4];
+    int cnt[4], nrec, gn[4];
+    float first_af[4], rest[4];
+};
+
+__device__ __forceinline__ void part16_put(Red16Shared &sh, const int slot, const int lane, const Part16 &a)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        sh.snt[slot][nt][lane] = a.snt[0][nt]; sh.snt[slot][4 + nt][lane] = a.snt[1][nt];
+        sh.srd[slot][nt][lane] = a.srd[0][nt]; sh.srd[slot][4 + nt][lane] = a.srd[1][nt];
+        sh.ints[slot][nt][lane] = a.cnt[nt];
+        sh.ints[slot][5 + nt][lane] = a.gn[nt];
+        sh.flts[slot][nt][lane] = a.first_af[nt];
+        sh.flts[slot][4 + nt][lane] = a.rest[nt];
+    }
+    sh.ints[slot][4][lane] = a.nrec;
+}
+
+// L = L (+) slot, L covering the earlier samples (lane_acc_merge, field by field out of LDS)
+__device__ __forceinline__ void part16_merge(Part16 &L, const Red16Shared &sh, const int slot, const int lane)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        L.snt[0][nt] += sh.snt[slot][nt][lane]; L.snt[1][nt] += sh.snt[slot][4 + nt][lane];
+        L.srd[0][nt] += sh.srd[slot][nt][lane]; L.srd[1][nt] += sh.srd[slot][4 + nt][lane];
+        L.cnt[nt] += sh.ints[slot][nt][lane];
+        const int rn = sh.ints[slot][5 + nt][lane];
+        if (rn != 0) {
+            const float rf = sh.flts[slot][nt][lane], rr = sh.flts[slot][4 + nt][lane];
+            if (L.gn[nt] == 0) {
+                L.first_af[nt] = rf; L.rest[nt] = rr;
+            } else {
+                float m = L.rest[nt];
+                if (m <= rf) m = rf;
+                if (m <= rr) m = rr;
+                L.rest[nt] = m;
+            }
+            L.gn[nt] += rn;
+        }
+    }
+    L.nrec += sh.ints[slot][4][lane];
+}
+
+__global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView rv, const long long P, const int S, const int chunk_len,
+                                                                  const float C, const int cov, int *__restrict__ flags, const FinOut fin)
+{
+    __shared__ Red16Shared sh;
+    constexpr int RB = 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long p_raw = (long long)blockIdx.x * 64 + lane;
+    const bool valid = p_raw < P;
+    const long long p = valid ? p_raw : P - 1; // clamp: out-of-range lanes re-read the last position, never store
+    const int s0 = min(S, wave * chunk_len);
+    const int s1 = min(S, s0 + chunk_len);
+    Fast16 f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f.sx[0][nt] = f.sx[1][nt] = 0; f.sd[0][nt] = f.sd[1][nt] = 0; f.sp[0][nt] = f.sp[1][nt] = 0.0;
+        f.gn[nt] = 0; f.gfa[nt] = 0.0f; f.gbx[nt] = 0; f.gbd[nt] = 1; f.zmask[nt] = ~0ull;
+    }
+    f.cnt01 = f.cnt23 = 0u;
+    f.nrec_bad = 0u;
+    const size_t row_step = (size_t)rv.row_stride * RB;
+    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;
+    // Two rows per trip, two named register sets: row s + 1 is in flight while row s is consumed and row s + 2 while row s + 1
+    // is.  (Written as one row per trip with a "next" record, hipcc copies the freshly loaded record into the loop-carried
+    // registers at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none;
+    // that form ran at 166 us on config 3 against the general kernel's 124.)  Rows past the chunk are loaded (clamped to the
+    // last sample row) and not visited.
+    RawRec<AMPLI_RECORDS_U16> ra = rec_load_at<AMPLI_RECORDS_U16>(q), rb;
+    for (int i = 0; i < chunk_len; i += 2) {
+        const int s = s0 + i;
+        if (s + 1 < S) q += row_step;
+        rb = rec_load_at<AMPLI_RECORDS_U16>(q);
+        {
+            int4 c0, c1;
+            rec_decode<AMPLI_RECORDS_U16>(ra, c0, c1);
+            if (s < s1) visit16(f, c0, c1, C, cov);
+        }
+        if (s + 2 < S) q += row_step;
+        ra = rec_load_at<AMPLI_RECORDS_U16>(q);
+        {
+            int4 c0, c1;
+            rec_decode<AMPLI_RECORDS_U16>(rb, c0, c1);
+            if (s + 1 < s1) visit16(f, c0, c1, C, cov);
+        }
+    }
+    if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)FAST_MAX_RECORDS) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
+    Part16 a;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            a.snt[st][nt] = (double)f.sx[st][nt] + f.sp[st][nt];
+            a.srd[st][nt] = (long long)f.sd[st][nt];
+        }
+        a.gn[nt] = f.gn[nt];
+        a.first_af[nt] = f.gfa[nt];
+        a.rest[nt] = f.gn[nt] > 1 ? (float)f.gbx[nt] / (float)f.gbd[nt] : -INFINITY;
+    }
+    a.cnt[0] = (int)(f.cnt01 & 0xFFFFu); a.cnt[1] = (int)(f.cnt01 >> 16);
+    a.cnt[2] = (int)(f.cnt23 & 0xFFFFu); a.cnt[3] = (int)(f.cnt23 >> 16);
+    a.nrec = (int)(f.nrec_bad & 0x7FFFFFFFu);
+    // the four chunks in sample order, a tree over adjacent chunks: waves 1, 3 hand over to 0, 2; then 2 to 0
+    if (wave & 1) part16_put(sh, wave >> 1, lane, a);
+    __syncthreads();
+    if (!(wave & 1)) part16_merge(a, sh, wave >> 1, lane);
+    __syncthreads();
+    if (wave == 2) part16_put(sh, 0, lane, a);
+    __syncthreads();
+    if (wave == 0) {
+        part16_merge(a, sh, 0, lane);
+        if (valid) {
+            const double limit = envelope_limit(C, cov);
+            bool bad = false;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                bad |= finalize_one(nt, a.snt[0][nt], a.snt[1][nt], a.srd[0][nt], a.srd[1][nt], a.cnt[nt], a.nrec, a.gn[nt], a.rest[nt], P, p_raw, limit, fin);
+            if (bad && fin.flags) atomicOr(fin.flags, 1);
         }
     }
 }
@@ -1933,6 +2142,12 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         kfin.accumulate = 0;   // folded in by the merge kernel, below
     }
     if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
+    if (ctx->reduce_compact && fast && G == 1 && splits == 1 && co.layout == AMPLI_RECORDS_U16 && !d_acc && fin.rate && !fin.packed &&
+        !fin.slice_len && !fin.accumulate && E == 0 && S <= RED_WAVES * FAST_MAX_CHUNK) {
+        hipLaunchKernelGGL(error_reduce_u16_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, co.rv, (long long)P, (int)S,
+                           (S + RED_WAVES - 1) / RED_WAVES, C, (int)cov, ctx->d_flags, fin);
+        return check_launch(ctx, "error_reduce_u16_kernel");
+    }
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE_L(FASTV, GV, UV)                                                                                      \
     hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P, \

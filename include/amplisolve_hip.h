@@ -459,6 +459,11 @@ int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_r
  * kernel that follows the reference operation by operation for any depth (slower).  reduce_lane_groups: lane
  * groups per wave of error_reduce (1, 2 or 4; 0 = automatic: 1 unless the panel is too small to fill the chip). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general, int32_t reduce_lane_groups);
+/* error_reduce for uint16 records with a compact per-position state (96 VGPRs: five waves per SIMD instead of four): taken by
+ * ampli_error_estimate / ampli_error_reduce_records when on != 0 (the default) and the launch has the shape it covers -- fast
+ * kernel, uint16 records, no position listed twice, one lane group, one sample split, fused finalize, no accumulator table, at
+ * most 4096 samples; every other launch takes the general kernel.  Same results, bit for bit. */
+int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
 
 /* poisson_call (prefilter mode) launch shape; 0 = default for each.  rows_per_wave: tumour rows one wave streams
  * (a workgroup = 4 waves over one 64-record tile and 4 * rows_per_wave rows).  drain_blocks_per_shard: workgroups per

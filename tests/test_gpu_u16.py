@@ -193,3 +193,32 @@ def test_error_reduce_u16_largest_depths(ctx16):
         assert ctx16.flags() == 0
         assert_acc_equal(acc, ref)
     assert_final_equal(ctx16.error_estimate(to16(ctx16, recs), P, 0.002, 100), orc.error_finalize(ref))
+
+
+@pytest.mark.parametrize("P,S", [(1, 1), (63, 2), (64, 3), (65, 4), (1000, 33), (4097, 37), (777, 130), (300, 700), (20000, 256), (130, 4096)])
+def test_error_estimate_compact_state_kernel(ctx16, P, S):
+    """error_reduce_u16_kernel (round 4: uint16 records, compact per-position state, five waves per SIMD; the default for the
+    launches it covers) against the general kernel and the oracle: the same table, bit for bit -- synthetic cohorts with edge-case
+    records mixed in (absent cells, depth around the cutoff, AF around 5 %, empty strands, first qualifying records late in a chunk)."""
+    recs = synth_recs(P, S)
+    rng = np.random.default_rng(P * 1000 + S)
+    if P >= 63:
+        e = edge_case_recs(P, S, rng)
+        pick = rng.random((S, P)) < 0.3
+        recs[pick] = e[pick]
+    want = orc.error_finalize(orc.error_reduce(recs, P, 0.002, 100))
+    packed = to16(ctx16, recs)
+    outs = []
+    for compact in (True, False):
+        ctx16.set_reduce_compact(compact)
+        try:
+            got = ctx16.error_estimate(packed, P, 0.002, 100)
+            assert ctx16.flags() == 0
+        finally:
+            ctx16.set_reduce_compact(True)
+        assert_final_equal(got, want)
+        outs.append(got)
+    import torch
+
+    for k in ("rate", "thr", "code", "germ_present"):
+        assert torch.equal(getattr(outs[0], k).view(torch.uint8), getattr(outs[1], k).view(torch.uint8)), k
