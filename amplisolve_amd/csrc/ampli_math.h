@@ -32,9 +32,12 @@
 #define AMPLI_AF_MID_SHIFT 29
 #define AMPLI_COUNT_LIMIT (1 << 24)
 
+// floor(d * 26843545 / 2^29) = floor(d * (26843545 * 8) / 2^32): the high half of ONE 32 x 32-bit multiply (v_mul_hi_u32)
+// instead of a 64-bit multiply-add and a 64-bit shift; 26843545 * 8 < 2^32, so the identity holds for every uint32 d.
+#define AMPLI_AF_MID_NUM8 214748360u
 AMPLI_FN int32_t ampli_af_limit(int32_t d)
 {
-    return (int32_t)(((uint64_t)(uint32_t)d * AMPLI_AF_MID_NUM) >> AMPLI_AF_MID_SHIFT);
+    return (int32_t)(((uint64_t)(uint32_t)d * AMPLI_AF_MID_NUM8) >> 32);
 }
 
 // literal form, for operands outside the exact-float range and for tests
