@@ -658,7 +658,8 @@ constexpr double SLIM_C2 = 17179869184.0;    // 2^34
 __host__ __device__ constexpr int slice_planes(const int fmt) { return fmt == AMPLI_SLICE_SLIM ? 14 : 21; }
 
 // slice-major stores for the reduce-scatter merge: each destination rank's slice is one contiguous chunk
-__device__ __forceinline__ void lane_acc_store_sliced(const FinOut &o, const long long p, const LaneAcc &a)
+// (Acc: LaneAcc, or the compact kernel's Part16 -- the same fields under the same names)
+template <class Acc> __device__ __forceinline__ void lane_acc_store_sliced(const FinOut &o, const long long p, const Acc &a)
 {
     const long long L = o.slice_len, k = p / L, q = p - k * L;
     double *__restrict__ pk = o.sl_sums + (size_t)k * o.sl_group * slice_planes(o.sl_fmt) * L + q;
@@ -1082,7 +1083,8 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
 //   * nrec and the "depth beyond the fast envelope" bit share a register;
 //   * the epilogue combines the four chunks field by field through LDS and finalises nucleotide by nucleotide.
 // Only the headline's shape, like every specialisation here: fast arithmetic, one lane group, one sample split, no position
-// listed twice, finalize fused, no accumulator table; everything else takes error_reduce_kernel.  Same results, bit for bit.
+// listed twice, no accumulator table -- the table finalised in the epilogue (one GPU) or the shard's sums stored slice-major for
+// the multi-GPU exchange; everything else takes error_reduce_kernel.  Same results, bit for bit.
 // ---------------------------------------------------------------------------
 struct Fast16 {
     int sx[2][4];
@@ -1147,8 +1149,8 @@ struct Red16Shared {
 struct Part16 {
     double snt[2][4];
     long long srd[2][4];
-    int cnt[4], nrec, gn[4];
-    float first_af[4], rest[4];
+    int cnt[4], nrec, gm_n[4];
+    float gm_first_af[4], gm_rest[4];
 };
 
 __device__ __forceinline__ void part16_put(Red16Shared &sh, const int slot, const int lane, const Part16 &a)
@@ -1158,9 +1160,9 @@ __device__ __forceinline__ void part16_put(Red16Shared &sh, const int slot, cons
         sh.snt[slot][nt][lane] = a.snt[0][nt]; sh.snt[slot][4 + nt][lane] = a.snt[1][nt];
         sh.srd[slot][nt][lane] = a.srd[0][nt]; sh.srd[slot][4 + nt][lane] = a.srd[1][nt];
         sh.ints[slot][nt][lane] = a.cnt[nt];
-        sh.ints[slot][5 + nt][lane] = a.gn[nt];
-        sh.flts[slot][nt][lane] = a.first_af[nt];
-        sh.flts[slot][4 + nt][lane] = a.rest[nt];
+        sh.ints[slot][5 + nt][lane] = a.gm_n[nt];
+        sh.flts[slot][nt][lane] = a.gm_first_af[nt];
+        sh.flts[slot][4 + nt][lane] = a.gm_rest[nt];
     }
     sh.ints[slot][4][lane] = a.nrec;
 }
@@ -1176,15 +1178,15 @@ __device__ __forceinline__ void part16_merge(Part16 &L, const Red16Shared &sh, c
         const int rn = sh.ints[slot][5 + nt][lane];
         if (rn != 0) {
             const float rf = sh.flts[slot][nt][lane], rr = sh.flts[slot][4 + nt][lane];
-            if (L.gn[nt] == 0) {
-                L.first_af[nt] = rf; L.rest[nt] = rr;
+            if (L.gm_n[nt] == 0) {
+                L.gm_first_af[nt] = rf; L.gm_rest[nt] = rr;
             } else {
-                float m = L.rest[nt];
+                float m = L.gm_rest[nt];
                 if (m <= rf) m = rf;
                 if (m <= rr) m = rr;
-                L.rest[nt] = m;
+                L.gm_rest[nt] = m;
             }
-            L.gn[nt] += rn;
+            L.gm_n[nt] += rn;
         }
     }
     L.nrec += sh.ints[slot][4][lane];
@@ -1244,9 +1246,9 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
             a.snt[st][nt] = (double)f.sx[st][nt] + f.sp[st][nt];
             a.srd[st][nt] = (long long)f.sd[st][nt];
         }
-        a.gn[nt] = f.gn[nt];
-        a.first_af[nt] = f.gfa[nt];
-        a.rest[nt] = f.gn[nt] > 1 ? (float)f.gbx[nt] / (float)f.gbd[nt] : -INFINITY;
+        a.gm_n[nt] = f.gn[nt];
+        a.gm_first_af[nt] = f.gfa[nt];
+        a.gm_rest[nt] = f.gn[nt] > 1 ? (float)f.gbx[nt] / (float)f.gbd[nt] : -INFINITY;
     }
     a.cnt[0] = (int)(f.cnt01 & 0xFFFFu); a.cnt[1] = (int)(f.cnt01 >> 16);
     a.cnt[2] = (int)(f.cnt23 & 0xFFFFu); a.cnt[3] = (int)(f.cnt23 >> 16);
@@ -1261,12 +1263,15 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
     if (wave == 0) {
         part16_merge(a, sh, 0, lane);
         if (valid) {
-            const double limit = envelope_limit(C, cov);
-            bool bad = false;
+            if (fin.slice_len) lane_acc_store_sliced(fin, p_raw, a); // multi-GPU shard, sliced exchange: straight into the exchange buffers
+            if (fin.rate) {
+                const double limit = envelope_limit(C, cov);
+                bool bad = false;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                bad |= finalize_one(nt, a.snt[0][nt], a.snt[1][nt], a.srd[0][nt], a.srd[1][nt], a.cnt[nt], a.nrec, a.gn[nt], a.rest[nt], P, p_raw, limit, fin);
-            if (bad && fin.flags) atomicOr(fin.flags, 1);
+                for (int nt = 0; nt < 4; ++nt)
+                    bad |= finalize_one(nt, a.snt[0][nt], a.snt[1][nt], a.srd[0][nt], a.srd[1][nt], a.cnt[nt], a.nrec, a.gm_n[nt], a.gm_rest[nt], P, p_raw, limit, fin);
+                if (bad && fin.flags) atomicOr(fin.flags, 1);
+            }
         }
     }
 }
@@ -2142,8 +2147,8 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         kfin.accumulate = 0;   // folded in by the merge kernel, below
     }
     if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
-    if (ctx->reduce_compact && fast && G == 1 && splits == 1 && co.layout == AMPLI_RECORDS_U16 && !d_acc && fin.rate && !fin.packed &&
-        !fin.slice_len && !fin.accumulate && E == 0 && S <= RED_WAVES * FAST_MAX_CHUNK) {
+    if (ctx->reduce_compact && fast && G == 1 && splits == 1 && co.layout == AMPLI_RECORDS_U16 && !d_acc && (fin.rate || fin.slice_len) && !fin.packed &&
+        !fin.accumulate && E == 0 && S <= RED_WAVES * FAST_MAX_CHUNK) {
         hipLaunchKernelGGL(error_reduce_u16_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, co.rv, (long long)P, (int)S,
                            (S + RED_WAVES - 1) / RED_WAVES, C, (int)cov, ctx->d_flags, fin);
         return check_launch(ctx, "error_reduce_u16_kernel");

@@ -927,8 +927,10 @@ def main():
         red_bytes = rec_bytes * P * S + (((8 * merger.planes + 32) * P if sliced else acc_bytes) if multi else 88 * P)
         call_bytes = rec_bytes * P * T + 33 * P + P * T    # poisson_call: records + thresholds/ref + mask
         lay = {"i32": 0, "u16": 1, "u24": 2}[layout]
+        # uint16 records without positions listed twice go through the compact-state kernel (five waves per SIMD; csrc/ampli_kernels.hip)
+        red_name = "error_reduce_u16_kernel" if layout == "u16" else f"error_reduce_kernel<true, 1, {lay}>"
         if t_red >= t_call:
-            dom, dom_ms, dom_bytes = f"error_reduce_kernel<true, 1, {lay}>", t_red, red_bytes
+            dom, dom_ms, dom_bytes = red_name, t_red, red_bytes
         else:
             dom, dom_ms, dom_bytes = f"poisson_stream_kernel<{lay}, false>+poisson_drain_kernel", t_call, call_bytes
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -951,7 +953,7 @@ def main():
         if t_red >= t_call:
             oth, oth_ms, oth_bytes = f"poisson_stream_kernel<{lay}, false>+poisson_drain_kernel", t_call, call_bytes
         else:
-            oth, oth_ms, oth_bytes = f"error_reduce_kernel<true, 1, {lay}>", t_red, red_bytes
+            oth, oth_ms, oth_bytes = red_name, t_red, red_bytes
         oth_traffic = None
         if traffic_src:
             try:

@@ -460,9 +460,10 @@ int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_r
  * groups per wave of error_reduce (1, 2 or 4; 0 = automatic: 1 unless the panel is too small to fill the chip). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general, int32_t reduce_lane_groups);
 /* error_reduce for uint16 records with a compact per-position state (96 VGPRs: five waves per SIMD instead of four): taken by
- * ampli_error_estimate / ampli_error_reduce_records when on != 0 (the default) and the launch has the shape it covers -- fast
- * kernel, uint16 records, no position listed twice, one lane group, one sample split, fused finalize, no accumulator table, at
- * most 4096 samples; every other launch takes the general kernel.  Same results, bit for bit. */
+ * ampli_error_estimate / ampli_error_reduce_records / ampli_error_reduce_sliced when on != 0 (the default) and the launch has the
+ * shape it covers -- fast kernel, uint16 records, no position listed twice, one lane group, one sample split, no accumulator
+ * table (finalize fused, or the shard's sums straight into the sliced exchange buffers), at most 4096 samples; every other
+ * launch takes the general kernel.  Same results, bit for bit. */
 int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
 
 /* poisson_call (prefilter mode) launch shape; 0 = default for each.  rows_per_wave: tumour rows one wave streams

@@ -222,3 +222,47 @@ def test_error_estimate_compact_state_kernel(ctx16, P, S):
 
     for k in ("rate", "thr", "code", "germ_present"):
         assert torch.equal(getattr(outs[0], k).view(torch.uint8), getattr(outs[1], k).view(torch.uint8)), k
+
+
+@pytest.mark.parametrize("slim", [False, True])
+@pytest.mark.parametrize("P,S,n", [(4097, 64, 8), (1000, 37, 3), (20000, 256, 2)])
+def test_sliced_merge_through_the_compact_kernel(ctx16, P, S, n, slim):
+    """A shard of a multi-GPU panel on uint16 records goes through error_reduce_u16_kernel too (sums and germ-max pairs straight
+    into the slice-major exchange buffers, both formats of the sums): the merged table is the single pass's, with the compact
+    kernel and with the general one."""
+    import torch
+
+    from amplisolve_amd.dist import shard_range, slice_geometry, slice_planes
+
+    recs = synth_recs(P, S)
+    rng = np.random.default_rng(P + S)
+    e = edge_case_recs(P, S, rng)
+    pick = rng.random((S, P)) < 0.2
+    recs[pick] = e[pick]
+    ref = orc.error_finalize(orc.error_reduce(recs, P))
+    L, _, _, bb = slice_geometry(P, n, slim)
+    pl = slice_planes(slim)
+    ctx16.set_slice_format(slim)
+    ctx16.set_tuning(1, groups=1)  # one sample split, one lane group: the shape the compact kernel takes (uint16 records only)
+    try:
+        for compact in (True, False):
+            ctx16.set_reduce_compact(compact)
+            sums, gms = [], []
+            for r in range(n):
+                a, b = shard_range(S, r, n)
+                s = torch.zeros(n * pl * L, dtype=torch.float64, device="cuda")
+                g = torch.zeros(n * 8 * L, dtype=torch.float32, device="cuda")
+                ctx16.error_reduce_sliced(to16(ctx16, recs[a:b]), P, n, s, g, first_sample=a)
+                sums.append(s)
+                gms.append(g)
+            assert ctx16.flags() == 0
+            total = torch.stack(sums).sum(0).view(n, pl * L)
+            blocks = torch.zeros(n * bb, dtype=torch.uint8, device="cuda")
+            for k in range(n):
+                recv = torch.stack([g.view(n, 8 * L)[k] for g in gms]).contiguous()
+                ctx16.error_finalize_slice(P, n, k, total[k].contiguous(), recv, blocks[k * bb:(k + 1) * bb])
+            assert_final_equal(ctx16.error_table_unslice(P, n, blocks), ref)
+    finally:
+        ctx16.set_reduce_compact(True)
+        ctx16.set_tuning(0)
+        ctx16.set_slice_format(False)
