@@ -110,6 +110,7 @@ HIP_SYMBOLS = {
     "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),
     "ampli_synth_ref": (C.c_int, [vp, vp, i64, u64]),
     "ampli_set_reduce_compact": (C.c_int, [vp, i32]),
+    "ampli_last_reduce_kernel": (C.c_int, [vp]),
     "ampli_set_tuning": (C.c_int, [vp, i32, i32, i32]),
     "ampli_ctx_flags": (C.c_int, [vp, C.POINTER(i32), i32]),
     "ampli_set_queue_items": (C.c_int, [vp, i64]),

@@ -170,6 +170,12 @@ class Context:
     def set_tuning(self, reduce_splits: int = 0, general: bool = False, groups: int = 0):
         self._check(self.lib.ampli_set_tuning(self.h, reduce_splits, int(general), groups))
 
+    def last_reduce_kernel(self) -> str:
+        """the kernel the latest error_reduce launch of this context was"""
+        k = self.lib.ampli_last_reduce_kernel(self.h)
+        self._check(min(k, 0))
+        return "error_reduce_u16_kernel" if k == 1 else "error_reduce_kernel"
+
     # ---- hipGraph capture ---------------------------------------------------------------
     def graph_begin(self):
         self._check(self.lib.ampli_graph_begin(self.h))

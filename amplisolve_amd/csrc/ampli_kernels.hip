@@ -304,6 +304,11 @@ extern "C" int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on)
     return AMPLI_OK;
 }
 
+extern "C" int ampli_last_reduce_kernel(const ampli_ctx *ctx)
+{
+    return ctx && ctx->last_reduce_kernel >= 0 ? ctx->last_reduce_kernel : AMPLI_E_INVALID;
+}
+
 extern "C" int ampli_set_poisson_tuning(ampli_ctx *ctx, int32_t rows_per_wave, int32_t drain_blocks_per_shard)
 {
     if (!ctx || rows_per_wave < 0 || drain_blocks_per_shard < 0 || drain_blocks_per_shard > 65535) return AMPLI_E_INVALID;
@@ -814,6 +819,17 @@ __device__ __forceinline__ unsigned long long mul24x24(int a, int b)
     return (unsigned long long)((unsigned)a & 0xFFFFFFu) * (unsigned long long)((unsigned)b & 0xFFFFFFu);
 }
 
+// the same as two named instructions (both full rate, both read only the low 24 bits of their operands): left to itself
+// hipcc turns some of these products into v_mad_u64_u32, which takes four passes
+__device__ __forceinline__ unsigned long long mul24x24_pair(int a, int b)
+{
+    unsigned lo, hi;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define AF_LIMIT_F32 0x1.999998p-5f
+
 // LEAN: the caller guarantees a full, converged wave (no lane group / extras divergence) and keeps a.zmask current.
 template <bool LEAN>
 __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4 r1, const int sample, const float C,
@@ -1091,11 +1107,10 @@ struct Fast16 {
     int sd[2][4];
     double sp[2][4];
     unsigned cnt01, cnt23; // cnt[0] | cnt[1] << 16, cnt[2] | cnt[3] << 16
-    int gn[4];
     float gfa[4];          // AF of the first qualifying record (EE:1229-1232); its value is dropped by the reference (EE:1258-1261)
     int gbx[4], gbd[4];    // best later record as a fraction (0/1 until one exists)
     unsigned nrec_bad;     // nrec | bad << 31
-    unsigned long long zmask[4];
+    unsigned long long zmask[4], lmask[4]; // wave masks (scalar registers): no first record yet | a later one met
 };
 
 __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1, const float C, const int cov)
@@ -1106,14 +1121,19 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
     const int FW = fw[0] + fw[1] + fw[2] + fw[3];  // EE:1175
     const int BW = bw[0] + bw[1] + bw[2] + bw[3];  // EE:1176
     const int RD = FW + BW;
-    const bool covok = present && FW >= cov && BW >= cov; // EE:1595, EE:1251
+    // EE:1595, EE:1251; an absent record has fw[0] = INT32_MIN, so its FW is negative and fails by itself (one compare feeds the
+    // wave mask below directly; with "present &&" in front the mask takes a v_cndmask / v_cmp round trip per row)
+    const unsigned long long covmask = __builtin_amdgcn_sicmp(min(FW, BW), cov, 39 /*sge*/);
+    const bool covok = __builtin_amdgcn_inverse_ballot_w64(covmask);
     a.nrec_bad += present ? 1u : 0u;               // EE:1659
-    if (!__any(covok)) return;
+    if (covmask == 0) return;
     // RD < 2^19 for uint16 records: never beyond FAST_COUNT_LIMIT; the bit stays for the records-per-lane check
-    const int lim_fw = ampli_af_limit(FW), lim_bw = ampli_af_limit(BW), lim_rd = ampli_af_limit(RD);
-    const double prod_fw = (double)((float)FW * C); // EE:1597
-    const double prod_bw = (double)((float)BW * C); // EE:1599
-    const unsigned long long covmask = __builtin_amdgcn_ballot_w64(covok);
+    // ampli_af_limit(d) = floor(d * 26843545 / 2^29) as one float multiply: the same integer for every d < 2^24
+    // (tests/test_math_host.py checks all of them), full rate where v_mul_hi_u32 takes four passes
+    const float fFW = (float)FW, fBW = (float)BW, fRD = (float)RD;
+    const int lim_fw = (int)(fFW * AF_LIMIT_F32), lim_bw = (int)(fBW * AF_LIMIT_F32), lim_rd = (int)(fRD * AF_LIMIT_F32);
+    const double prod_fw = (double)(fFW * C); // EE:1597
+    const double prod_bw = (double)(fBW * C); // EE:1599
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
@@ -1123,18 +1143,22 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
             else a.cnt23 += nt == 2 ? 1u : 65536u;
         }
         const int x = fw[nt] + bw[nt];
-        const bool pass = covok && x <= lim_rd; // EE:1251: float(X)/float(RD) <= 0.05
-        bool cand = pass;
-        if ((__builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask) & a.zmask[nt]) {
-            const bool is_first = pass && a.gn[nt] == 0;
-            if (is_first) { a.gfa[nt] = (float)x / (float)RD; a.gn[nt] = 1; } // EE:1229-1232
-            a.zmask[nt] = __builtin_amdgcn_ballot_w64(a.gn[nt] == 0);
-            cand = pass && !is_first;
+        // EE:1251: float(X)/float(RD) <= 0.05.  The Germ_Max state machine of EE:1229-1271 in wave masks: zmask = lanes that have not
+        // met their first qualifying record, lmask = lanes that have met a later one (all a reader ever asks of the count)
+        const unsigned long long passmask = __builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask;
+        unsigned long long candmask = passmask;
+        const unsigned long long firstmask = passmask & a.zmask[nt];
+        if (firstmask) { // rare: in steady state every passing lane already holds its first record
+            if (__builtin_amdgcn_inverse_ballot_w64(firstmask)) a.gfa[nt] = (float)x / fRD; // EE:1229-1232
+            a.zmask[nt] &= ~firstmask;
+            candmask &= ~firstmask;
         }
-        const bool better = cand && mul24x24(x, a.gbd[nt]) > mul24x24(a.gbx[nt], RD); // EE:1266, ties keep the value
+        a.lmask[nt] |= candmask;
+        // EE:1266 by cross-multiplication, ties keep the value
+        const unsigned long long gtmask = __builtin_amdgcn_uicmpl(mul24x24_pair(x, a.gbd[nt]), mul24x24_pair(a.gbx[nt], RD), 34 /*ugt*/);
+        const bool better = __builtin_amdgcn_inverse_ballot_w64(candmask & gtmask);
         a.gbx[nt] = better ? x : a.gbx[nt];
         a.gbd[nt] = better ? RD : a.gbd[nt];
-        a.gn[nt] += cand ? 1 : 0;
     }
 }
 
@@ -1208,7 +1232,7 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         f.sx[0][nt] = f.sx[1][nt] = 0; f.sd[0][nt] = f.sd[1][nt] = 0; f.sp[0][nt] = f.sp[1][nt] = 0.0;
-        f.gn[nt] = 0; f.gfa[nt] = 0.0f; f.gbx[nt] = 0; f.gbd[nt] = 1; f.zmask[nt] = ~0ull;
+        f.gfa[nt] = 0.0f; f.gbx[nt] = 0; f.gbd[nt] = 1; f.zmask[nt] = ~0ull; f.lmask[nt] = 0ull;
     }
     f.cnt01 = f.cnt23 = 0u;
     f.nrec_bad = 0u;
@@ -1219,22 +1243,31 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
     // registers at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none;
     // that form ran at 166 us on config 3 against the general kernel's 124.)  Rows past the chunk are loaded (clamped to the
     // last sample row) and not visited.
-    RawRec<AMPLI_RECORDS_U16> ra = rec_load_at<AMPLI_RECORDS_U16>(q), rb;
-    for (int i = 0; i < chunk_len; i += 2) {
+    RawRec<AMPLI_RECORDS_U16> ra = rec_load_at<AMPLI_RECORDS_U16>(q), rb, rc;
+    if (s0 + 1 < S) q += row_step;
+    rb = rec_load_at<AMPLI_RECORDS_U16>(q);
+    for (int i = 0; i < chunk_len; i += 3) {
         const int s = s0 + i;
-        if (s + 1 < S) q += row_step;
-        rb = rec_load_at<AMPLI_RECORDS_U16>(q);
+        if (s + 2 < S) q += row_step;
+        rc = rec_load_at<AMPLI_RECORDS_U16>(q);
         {
             int4 c0, c1;
             rec_decode<AMPLI_RECORDS_U16>(ra, c0, c1);
             if (s < s1) visit16(f, c0, c1, C, cov);
         }
-        if (s + 2 < S) q += row_step;
+        if (s + 3 < S) q += row_step;
         ra = rec_load_at<AMPLI_RECORDS_U16>(q);
         {
             int4 c0, c1;
             rec_decode<AMPLI_RECORDS_U16>(rb, c0, c1);
             if (s + 1 < s1) visit16(f, c0, c1, C, cov);
+        }
+        if (s + 4 < S) q += row_step;
+        rb = rec_load_at<AMPLI_RECORDS_U16>(q);
+        {
+            int4 c0, c1;
+            rec_decode<AMPLI_RECORDS_U16>(rc, c0, c1);
+            if (s + 2 < s1) visit16(f, c0, c1, C, cov);
         }
     }
     if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)FAST_MAX_RECORDS) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
@@ -1246,9 +1279,11 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
             a.snt[st][nt] = (double)f.sx[st][nt] + f.sp[st][nt];
             a.srd[st][nt] = (long long)f.sd[st][nt];
         }
-        a.gm_n[nt] = f.gn[nt];
+        // qualifying records of the chunk, saturated at two: every reader asks "none, one, or more" (lane_acc_merge's sums keep that)
+        const bool none = (f.zmask[nt] >> lane) & 1, later = (f.lmask[nt] >> lane) & 1;
+        a.gm_n[nt] = none ? 0 : later ? 2 : 1;
         a.gm_first_af[nt] = f.gfa[nt];
-        a.gm_rest[nt] = f.gn[nt] > 1 ? (float)f.gbx[nt] / (float)f.gbd[nt] : -INFINITY;
+        a.gm_rest[nt] = later ? (float)f.gbx[nt] / (float)f.gbd[nt] : -INFINITY;
     }
     a.cnt[0] = (int)(f.cnt01 & 0xFFFFu); a.cnt[1] = (int)(f.cnt01 >> 16);
     a.cnt[2] = (int)(f.cnt23 & 0xFFFFu); a.cnt[3] = (int)(f.cnt23 >> 16);
@@ -2106,15 +2141,23 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
     // lane groups per wave: only for panels too small to fill the chip with 64-position waves (measured on c3:
     // G = 2 / 4 cost 6 % / 11 % -- the narrower per-row segments outweigh the shorter tail)
     const long long resident_waves = (long long)ctx->n_cu * 16;
+    const bool fast = !ctx->reduce_general && !co.rv.rd && !co.rv.rd_ext; // lines with their own RD column: the literal kernel
+    // the shape error_reduce_u16_kernel takes (below).  From one tile per CU on it beats every cut of the general kernel along
+    // lanes or samples (tools/sweep_tiles.py: 48 us against 62 at 768 tiles, 69 against 102 at 1280), so such a launch is not cut
+    const bool compact_shape = ctx->reduce_compact && fast && co.layout == AMPLI_RECORDS_U16 && !d_acc && (fin.rate || fin.slice_len) &&
+                               !fin.packed && !fin.accumulate && E == 0 && S <= RED_WAVES * FAST_MAX_CHUNK;
+    const bool compact_uncut = compact_shape && (P + 63) / 64 >= ctx->n_cu;
     int G = ctx->reduce_groups;
     if (G != 1 && G != 2 && G != 4) {
         G = 1;
-        while (G < 4 && ((P + 64 / G - 1) / (64 / G)) * RED_WAVES < resident_waves && S / (RED_WAVES * 2 * G) >= 8) G *= 2;
+        while (!compact_uncut && G < 4 && ((P + 64 / G - 1) / (64 / G)) * RED_WAVES < resident_waves && S / (RED_WAVES * 2 * G) >= 8) G *= 2;
     }
     const long long tiles = (P + 64 / G - 1) / (64 / G);
     // sample splits: enough waves to fill the chip (>= ~24 waves per CU), each lane group with >= 8 samples
     int splits = ctx->reduce_splits;
-    if (splits <= 0) {
+    if (splits <= 0 && compact_uncut && G == 1) {
+        splits = 1;
+    } else if (splits <= 0) {
         const long long want_waves = (long long)ctx->n_cu * 24;
         splits = (int)((want_waves + tiles * RED_WAVES - 1) / (tiles * RED_WAVES));
         const int max_splits = (S + RED_WAVES * G * 8 - 1) / (RED_WAVES * G * 8);
@@ -2122,7 +2165,6 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         if (splits < 1) splits = 1;
     }
     if (splits > S) splits = S;
-    const bool fast = !ctx->reduce_general && !co.rv.rd && !co.rv.rd_ext; // lines with their own RD column: the literal kernel
     if (fast) { // int32 partial sums: a lane takes at most FAST_MAX_CHUNK samples
         const int need = (S + RED_WAVES * G * FAST_MAX_CHUNK - 1) / (RED_WAVES * G * FAST_MAX_CHUNK);
         if (splits < need) splits = need;
@@ -2147,8 +2189,8 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         kfin.accumulate = 0;   // folded in by the merge kernel, below
     }
     if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
-    if (ctx->reduce_compact && fast && G == 1 && splits == 1 && co.layout == AMPLI_RECORDS_U16 && !d_acc && (fin.rate || fin.slice_len) && !fin.packed &&
-        !fin.accumulate && E == 0 && S <= RED_WAVES * FAST_MAX_CHUNK) {
+    ctx->last_reduce_kernel = compact_shape && G == 1 && splits == 1;
+    if (ctx->last_reduce_kernel) {
         hipLaunchKernelGGL(error_reduce_u16_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, co.rv, (long long)P, (int)S,
                            (S + RED_WAVES - 1) / RED_WAVES, C, (int)cov, ctx->d_flags, fin);
         return check_launch(ctx, "error_reduce_u16_kernel");

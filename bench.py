@@ -878,6 +878,8 @@ def main():
                 "poisson_call_ms": c_call, "poisson_call_frac_of_peak": (rec_bytes * P * T + 33 * P + P * T) / (c_call * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "note": "the same pass rotated over distinct resident batches (each pass reads records no earlier pass left in the 256 MiB Infinity "
                         "Cache); outside the contract's timed region, HIP events per pass"}
+        cold_pass(0, False)  # leave the timed batch's own table and call mask in the output buffers (compared with below)
+        torch.cuda.synchronize()
         if ctx.flags(clear=True) != 0:
             raise SystemExit("kernel flags raised in the cold-HBM block")
         del extra, sets
@@ -927,8 +929,11 @@ def main():
         red_bytes = rec_bytes * P * S + (((8 * merger.planes + 32) * P if sliced else acc_bytes) if multi else 88 * P)
         call_bytes = rec_bytes * P * T + 33 * P + P * T    # poisson_call: records + thresholds/ref + mask
         lay = {"i32": 0, "u16": 1, "u24": 2}[layout]
-        # uint16 records without positions listed twice go through the compact-state kernel (five waves per SIMD; csrc/ampli_kernels.hip)
-        red_name = "error_reduce_u16_kernel" if layout == "u16" else f"error_reduce_kernel<true, 1, {lay}>"
+        # the library says which kernel its latest error_reduce launch was (uint16 records without positions listed twice go
+        # through the compact-state kernel: five waves per SIMD; csrc/ampli_kernels.hip)
+        red_name = ctx.last_reduce_kernel()
+        if red_name == "error_reduce_kernel":
+            red_name = f"error_reduce_kernel<true, 1, {lay}>"
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = red_name, t_red, red_bytes
         else:

@@ -465,6 +465,9 @@ int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduc
  * table (finalize fused, or the shard's sums straight into the sliced exchange buffers), at most 4096 samples; every other
  * launch takes the general kernel.  Same results, bit for bit. */
 int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
+/* Which kernel the context's latest error_reduce launch was: 0 = error_reduce_kernel (general), 1 = error_reduce_u16_kernel
+ * (compact state); AMPLI_E_INVALID before the first launch.  For tests and the bench line, which name the kernel they measured. */
+int ampli_last_reduce_kernel(const ampli_ctx *ctx);
 
 /* poisson_call (prefilter mode) launch shape; 0 = default for each.  rows_per_wave: tumour rows one wave streams
  * (a workgroup = 4 waves over one 64-record tile and 4 * rows_per_wave rows).  drain_blocks_per_shard: workgroups per

@@ -195,7 +195,8 @@ def test_error_reduce_u16_largest_depths(ctx16):
     assert_final_equal(ctx16.error_estimate(to16(ctx16, recs), P, 0.002, 100), orc.error_finalize(ref))
 
 
-@pytest.mark.parametrize("P,S", [(1, 1), (63, 2), (64, 3), (65, 4), (1000, 33), (4097, 37), (777, 130), (300, 700), (20000, 256), (130, 4096)])
+@pytest.mark.parametrize("P,S", [(1, 1), (63, 2), (64, 3), (65, 4), (129, 5), (200, 6), (100, 7), (1000, 33), (4097, 37), (777, 130), (300, 700),
+                                 (20000, 256), (130, 4096)])
 def test_error_estimate_compact_state_kernel(ctx16, P, S):
     """error_reduce_u16_kernel (round 4: uint16 records, compact per-position state, five waves per SIMD; the default for the
     launches it covers) against the general kernel and the oracle: the same table, bit for bit -- synthetic cohorts with edge-case
@@ -211,11 +212,16 @@ def test_error_estimate_compact_state_kernel(ctx16, P, S):
     outs = []
     for compact in (True, False):
         ctx16.set_reduce_compact(compact)
+        # one sample split, one lane group: the shape the compact kernel takes (left to itself the library cuts panels this small
+        # along lanes or samples and they go through the general kernel)
+        ctx16.set_tuning(1 if compact else 0, groups=1 if compact else 0)
         try:
             got = ctx16.error_estimate(packed, P, 0.002, 100)
             assert ctx16.flags() == 0
+            assert ctx16.last_reduce_kernel() == ("error_reduce_u16_kernel" if compact and ctx16.layout_name == "u16" else "error_reduce_kernel")
         finally:
             ctx16.set_reduce_compact(True)
+            ctx16.set_tuning(0)
         assert_final_equal(got, want)
         outs.append(got)
     import torch
@@ -253,6 +259,7 @@ def test_sliced_merge_through_the_compact_kernel(ctx16, P, S, n, slim):
                 s = torch.zeros(n * pl * L, dtype=torch.float64, device="cuda")
                 g = torch.zeros(n * 8 * L, dtype=torch.float32, device="cuda")
                 ctx16.error_reduce_sliced(to16(ctx16, recs[a:b]), P, n, s, g, first_sample=a)
+                assert ctx16.last_reduce_kernel() == ("error_reduce_u16_kernel" if compact and ctx16.layout_name == "u16" else "error_reduce_kernel")
                 sums.append(s)
                 gms.append(g)
             assert ctx16.flags() == 0
