@@ -145,6 +145,7 @@ HOST_SYMBOLS = {
     "ampli_host_text_roundtrip_batch": (None, [vp, i64, vp]),
     "ampli_host_af_limit": (i32, [i32]),
     "ampli_host_af_limit_batch": (None, [vp, i64, vp]),
+    "ampli_host_af_limit_f32_batch": (None, [vp, i64, vp]),
     "ampli_host_prefilter_nocall": (C.c_int, [i32, i32, f32]),
     "ampli_host_prefilter_skip_f32": (C.c_int, [i32, i32, f32]),
     "ampli_host_drain_score_batch": (None, [vp, vp, vp, i64, vp, vp]),

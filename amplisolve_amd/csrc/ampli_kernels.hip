@@ -828,8 +828,6 @@ __device__ __forceinline__ unsigned long long mul24x24_pair(int a, int b)
     asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
     return ((unsigned long long)hi << 32) | lo;
 }
-#define AF_LIMIT_F32 0x1.999998p-5f
-
 // LEAN: the caller guarantees a full, converged wave (no lane group / extras divergence) and keeps a.zmask current.
 template <bool LEAN>
 __device__ __forceinline__ void visit_fast(FastAcc &a, const int4 r0, const int4 r1, const int sample, const float C,
@@ -1128,10 +1126,9 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
     a.nrec_bad += present ? 1u : 0u;               // EE:1659
     if (covmask == 0) return;
     // RD < 2^19 for uint16 records: never beyond FAST_COUNT_LIMIT; the bit stays for the records-per-lane check
-    // ampli_af_limit(d) = floor(d * 26843545 / 2^29) as one float multiply: the same integer for every d < 2^24
-    // (tests/test_math_host.py checks all of them), full rate where v_mul_hi_u32 takes four passes
+    // ampli_af_limit(d) as one float multiply (ampli_math.h): the same integer for every d < 2^24, and the floats are needed anyway
     const float fFW = (float)FW, fBW = (float)BW, fRD = (float)RD;
-    const int lim_fw = (int)(fFW * AF_LIMIT_F32), lim_bw = (int)(fBW * AF_LIMIT_F32), lim_rd = (int)(fRD * AF_LIMIT_F32);
+    const int lim_fw = ampli_af_limit_f32(fFW), lim_bw = ampli_af_limit_f32(fBW), lim_rd = ampli_af_limit_f32(fRD);
     const double prod_fw = (double)(fFW * C); // EE:1597
     const double prod_bw = (double)(fBW * C); // EE:1599
 #pragma unroll
@@ -1238,31 +1235,30 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
     f.nrec_bad = 0u;
     const size_t row_step = (size_t)rv.row_stride * RB;
     const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;
-    // Two rows per trip, two named register sets: row s + 1 is in flight while row s is consumed and row s + 2 while row s + 1
-    // is.  (Written as one row per trip with a "next" record, hipcc copies the freshly loaded record into the loop-carried
-    // registers at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none;
-    // that form ran at 166 us on config 3 against the general kernel's 124.)  Rows past the chunk are loaded (clamped to the
-    // last sample row) and not visited.
+    // Three named register sets in rotation: rows s + 1 and s + 2 are in flight while row s is consumed (s_waitcnt vmcnt(2)).
+    // (Written as one row per trip with a "next" record, hipcc copies the freshly loaded record into the loop-carried registers
+    // at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none; that form ran
+    // at 166 us on config 3 against the general kernel's 124; two sets, one row in flight: 107; three: 102.)  Past the end of
+    // the chunk the loads stay on its last row (cache hits) and the rows are not visited.
     RawRec<AMPLI_RECORDS_U16> ra = rec_load_at<AMPLI_RECORDS_U16>(q), rb, rc;
-    if (s0 + 1 < S) q += row_step;
+    if (s0 + 1 < s1) q += row_step;
     rb = rec_load_at<AMPLI_RECORDS_U16>(q);
-    for (int i = 0; i < chunk_len; i += 3) {
-        const int s = s0 + i;
-        if (s + 2 < S) q += row_step;
+    for (int s = s0; s < s1; s += 3) {
+        if (s + 2 < s1) q += row_step;
         rc = rec_load_at<AMPLI_RECORDS_U16>(q);
         {
             int4 c0, c1;
             rec_decode<AMPLI_RECORDS_U16>(ra, c0, c1);
             if (s < s1) visit16(f, c0, c1, C, cov);
         }
-        if (s + 3 < S) q += row_step;
+        if (s + 3 < s1) q += row_step;
         ra = rec_load_at<AMPLI_RECORDS_U16>(q);
         {
             int4 c0, c1;
             rec_decode<AMPLI_RECORDS_U16>(rb, c0, c1);
             if (s + 1 < s1) visit16(f, c0, c1, C, cov);
         }
-        if (s + 4 < S) q += row_step;
+        if (s + 4 < s1) q += row_step;
         rb = rec_load_at<AMPLI_RECORDS_U16>(q);
         {
             int4 c0, c1;

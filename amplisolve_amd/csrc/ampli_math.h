@@ -40,6 +40,15 @@ AMPLI_FN int32_t ampli_af_limit(int32_t d)
     return (int32_t)(((uint64_t)(uint32_t)d * AMPLI_AF_MID_NUM8) >> 32);
 }
 
+// The same integer as one fp32 multiply and a truncation, for 0 <= d < 2^24 (d exact in fp32): 0x1.999998p-5 is the float just
+// below 0.05, and the rounding error of the product never carries it across an integer that the exact quotient d * 26843545 / 2^29
+// has not crossed (tests/test_math_host.py compares every d).  Full rate on the GPU where v_mul_hi_u32 takes four passes; the
+// float of d is needed by the callers anyway.  Negative d (an absent record's sentinel sum) gives a value <= 0: callers mask it.
+AMPLI_FN int32_t ampli_af_limit_f32(float d_as_float)
+{
+    return (int32_t)(d_as_float * 0x1.999998p-5f);
+}
+
 // literal form, for operands outside the exact-float range and for tests
 AMPLI_FN int ampli_af_gate_fp(int32_t x, int32_t d)
 {

@@ -57,6 +57,11 @@ extern "C" void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *
     for (int64_t i = 0; i < n; ++i) out[i] = ampli_af_limit(d[i]);
 }
 
+extern "C" void ampli_host_af_limit_f32_batch(const int32_t *d, int64_t n, int32_t *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = ampli_af_limit_f32((float)d[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The synthetic panel as FILES (bench.py's end-to-end leg and the file-level tests): BED, reference-base table and one
 // .PILEUP.ASEQ per sample with exactly the counts ampli_synth_fill puts into HBM.  Panel = 30 amplicon regions on

@@ -35,6 +35,7 @@ int64_t ampli_host_synth_write_aseq(const char *dir, const char *prefix, int64_t
 void ampli_host_text_roundtrip_batch(const float *in, int64_t n, float *out);
 int32_t ampli_host_af_limit(int32_t d);
 void ampli_host_af_limit_batch(const int32_t *d, int64_t n, int32_t *out);
+void ampli_host_af_limit_f32_batch(const int32_t *d, int64_t n, int32_t *out); /* ampli_af_limit_f32((float)d[i]) */
 int ampli_host_prefilter_nocall(int32_t k, int32_t rd, float err);
 int ampli_host_prefilter_skip_f32(int32_t k, int32_t rd, float err); /* the streaming kernel's fp32 form */
 /* the all-scores mode's scorer (ampli_poisson_score_dense, csrc/ampli_math.h) on the host, lgamma computed: Q */

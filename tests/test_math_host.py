@@ -121,6 +121,23 @@ def test_af_gate_integer_bound_exhaustive_over_all_depths():
     assert (np.abs(lim - 0.05 * d.astype(np.float64)) <= 1).all()
 
 
+def test_af_limit_as_one_float_multiply_is_the_integer_limit_for_every_depth():
+    """error_reduce_u16_kernel forms the AF limit as (int)(float(d) * 0x1.999998p-5f) (full rate; the float of d is needed anyway):
+    the same integer as floor(d * 26843545 / 2^29) for EVERY depth the fast kernels accept, 0 <= d < 2^24."""
+    H = host_lib()
+    d = np.arange(0, 1 << 24, dtype=np.int32)
+    a, b = np.empty_like(d), np.empty_like(d)
+    H.ampli_host_af_limit_batch(d.ctypes.data_as(C.c_void_p), d.size, a.ctypes.data_as(C.c_void_p))
+    H.ampli_host_af_limit_f32_batch(d.ctypes.data_as(C.c_void_p), d.size, b.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(a, b)
+    assert np.array_equal(a.astype(np.uint64), (d.astype(np.uint64) * 26843545) >> 29)
+    # an absent record's strand sum is negative: whatever the limit is then, it is not positive (callers mask it anyway)
+    neg = np.array([-1, -100, -(1 << 23), -(2**31) + 5], np.int32)
+    out = np.empty_like(neg)
+    H.ampli_host_af_limit_f32_batch(neg.ctypes.data_as(C.c_void_p), neg.size, out.ctypes.data_as(C.c_void_p))
+    assert (out <= 0).all()
+
+
 def test_division_free_series_of_the_drain_kernel_is_the_reference_series():
     """The drain kernel scores queued items (k > m) with the series of VC:3785-3794 rewritten without divisions and
     without the early exit.  Against the oracle's literal scorer: p within 1e-9 relative everywhere (the contract is
