@@ -41,10 +41,9 @@ V = {
     "ps_lb6": [("template <int LAY, bool IRR>\n__global__ __launch_bounds__(256, 7) void poisson_stream_kernel(", "template <int LAY, bool IRR>\n__global__ __launch_bounds__(256, 6) void poisson_stream_kernel(")],
     # compact uint16 error_reduce kernel (round 4): four waves per SIMD instead of five (what does the occupancy buy on its own?)
     "c_lb4": [("__global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(", "__global__ __launch_bounds__(256, 4) void error_reduce_u16_kernel(")],
-    # ... the Germ_Max pass condition taken from the wave mask of ONE compare (the shipped form compares x <= limit twice: once as a lane
-    # bool, once through uicmp for the wave-uniform zmask test)
-    "c_onecmp": [("        const int x = fw[nt] + bw[nt];\n        const bool pass = covok && x <= lim_rd; // EE:1251: float(X)/float(RD) <= 0.05\n        bool cand = pass;\n        if ((__builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask) & a.zmask[nt]) {\n            const bool is_first = pass && a.gn[nt] == 0;\n            if (is_first) { a.gfa[nt]",
-                  "        const int x = fw[nt] + bw[nt];\n        const unsigned long long pm_ = __builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask;\n        const bool pass = __builtin_amdgcn_inverse_ballot_w64(pm_); // EE:1251: float(X)/float(RD) <= 0.05\n        bool cand = pass;\n        if (pm_ & a.zmask[nt]) {\n            const bool is_first = pass && a.gn[nt] == 0;\n            if (is_first) { a.gfa[nt]")],
+    # (measured on earlier forms of that kernel and folded into it or dropped, DESIGN.md 3.1: the pass condition from the wave mask of
+    #  ONE compare -- shipped since; signed cross products with a -1/1 sentinel instead of the "later record" mask -- 114 us, hipcc
+    #  keeps two copies of the numerator and branches around the update; two named record sets instead of three -- 107 against 102 us)
     # (three / five sample chunks per workgroup -- 192 / 320 threads, a tree over up to five waves in two LDS slots -- were measured
     #  with a generic form of the kernel's epilogue: 122-125 us / 128-131 us against 108-113 us with four)
     # poisson_stream without queue pushes
