@@ -14,10 +14,19 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port() -> str:
+    """a TCP port nobody on this host listens on right now (a fixed one collides with a run left over from another test session)"""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 @pytest.mark.parametrize("world,merge,group", [(2, "sliced", 1), (3, "sliced", 2), (2, "sliced", 4), (2, "allreduce", 1)])
 def test_bench_multirank_path_on_one_gpu(world, merge, group):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "7", "--warmup", "5",
+           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "7", "--warmup", "5",
            "--backend", "gloo", "--check", "--config", "c2", "--merge", merge, "--group", str(group)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -33,7 +42,7 @@ def test_rccl_calls_of_the_sliced_merge_on_a_size_one_communicator():
     on a real RCCL communicator -- of size 1, all a one-GPU box offers -- in the bench's pipeline shape, with
     poisson_call reading the gathered blocks."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29591", os.path.join(ROOT, "tools", "nccl_selftest.py")]
+           "--master-port", free_port(), os.path.join(ROOT, "tools", "nccl_selftest.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "nccl selftest ok" in r.stdout

@@ -12,7 +12,17 @@ BIN = os.path.join(ROOT, "amplisolve_amd", "bin")
 G = "/root/repo/tests/golden"  # the goldens were taken with this directory literal (it decides the visit order, EE:794-841)
 
 
+def free_port() -> int:
+    """a TCP port nobody on this host listens on right now"""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def torchrun(world, port, args, env=None):
+    port = free_port()  # the callers' literals only tell the launches apart when reading a failure
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "amplisolve_amd.multi"] + args
     e = dict(os.environ, AMPLISOLVE_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **(env or {}))
@@ -126,7 +136,7 @@ def test_failing_shard_ends_the_job(tmp_path):
     """A shard that cannot read its input fails the whole launch promptly (no hang in a collective) with the reason."""
     d = f"{G}/toy_subset"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29571", "-m", "amplisolve_amd.multi", "AmpliSolveVariantCalling", f"errorFile={tmp_path}/missing_table.txt",
+           "--master-port", str(free_port()), "-m", "amplisolve_amd.multi", "AmpliSolveVariantCalling", f"errorFile={tmp_path}/missing_table.txt",
            f"tumour_dir={d}/TUMOUR", f"output_dir={tmp_path}/o", "coverage_cutoff=100", "p_value=0.05"]
     e = dict(os.environ, AMPLISOLVE_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=e)
