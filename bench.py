@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--sustained", type=int, default=2000, help="passes of the sustained-rate block after the timed region (0 = skip)")
     ap.add_argument("--cold-batches", type=int, default=3, help="N = 1: distinct resident batches the cold-HBM block rotates over after the timed region "
                     "(no pass finds its inputs in the Infinity Cache); 0 or 1 = skip")
+    ap.add_argument("--whole-rounds", type=int, default=4, help="N = 1: after the timed region, time the dominant reduce kernel on a panel of this many "
+                    "whole rounds of resident workgroups (what the partly filled last round of the configuration costs); 0 = skip")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the reference's error estimation on ALL normals of config 3 (~6 min on one core)")
     ap.add_argument("--mode", default="prefilter", choices=["prefilter", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -884,6 +886,39 @@ def main():
             raise SystemExit("kernel flags raised in the cold-HBM block")
         del extra, sets
 
+    # error_reduce against the SIZE of its launch: config 3 is 1563 tiles of 64 positions on 1280 (compact kernel) or 1024 resident
+    # workgroups, i.e. one full round and a thin one; the same kernel on a panel of four whole rounds shows what the partly filled
+    # round costs (tools/sweep_tiles.py).  Outside the timed region; N = 1 only.
+    whole_rounds = None
+    if not multi and lanes is None and args.whole_rounds > 0:
+        kname = ctx.last_reduce_kernel()
+        # workgroups a CU holds: 96 VGPRs -> five waves per SIMD (compact kernel), 120 -> four (general); one wave of each of a CU's SIMDs per workgroup
+        per_round = torch.cuda.get_device_properties(dev_index).multi_processor_count * (5 if kname == "error_reduce_u16_kernel" else 4)
+        P2 = per_round * args.whole_rounds * 64
+        an2 = ctx.synth_fill(P2, S, seed=SEED, depth=depth)
+        if layout != "i32":
+            an2 = ctx.pack(an2, layout)[0]
+        f2 = ctx.error_estimate(an2, P2, 0.002, 100)
+        for _ in range(2):
+            ctx.error_estimate(an2, P2, 0.002, 100, out=f2)
+        ea, eb = ctx.event(), ctx.event()
+        ctx.record(ea)
+        for _ in range(10):
+            ctx.error_estimate(an2, P2, 0.002, 100, out=f2)
+        ctx.record(eb)
+        torch.cuda.synchronize()
+        t2 = ctx.elapsed_ms(ea, eb) / 10
+        b2 = rec_bytes * P2 * S + 88 * P2
+        whole_rounds = {"kernel": ctx.last_reduce_kernel(), "positions": P2, "tiles": P2 // 64, "resident_workgroups": per_round,
+                        "rounds_of_workgroups": args.whole_rounds, "config_rounds_of_workgroups": ((P + 63) // 64) / per_round,
+                        "avg_ms": t2, "algorithmic_bytes": b2, "achieved": b2 / (t2 * 1e-3) / 1e9, "unit": "GB/s",
+                        "frac": b2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "note": "the dominant kernel on a panel that is a whole number of rounds of resident workgroups (same samples per position, "
+                                "same layout), 10 launches back to back, HIP events; roofline.frac is the configuration's own launch"}
+        if ctx.flags(clear=True) != 0:
+            raise SystemExit("kernel flags raised in the whole-rounds block")
+        del an2, f2
+
     others = []
     for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and not multi and lanes is None]:
         # the same workload in the other record layouts, outside the timed region, for comparison
@@ -1028,6 +1063,8 @@ def main():
             out["sustained"] = sustained
         if cold:
             out["cold_hbm"] = cold
+        if whole_rounds:
+            out["roofline_whole_rounds"] = whole_rounds
         if multi:
             out["communication"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "merge": args.merge,
                                     "local_step_ms": t_local_ms, "exposed_ms_per_step": max(0.0, ms_per_step - t_local_ms),
