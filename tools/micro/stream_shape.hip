@@ -181,6 +181,33 @@ int main(int argc, char **argv)
         hipFree(d); hipFree(d_out);
         return 0;
     }
+    if (argc > 1 && atoi(argv[1]) == 16) { // round 4: the 16-byte stream (1 KB per wave and row) against rows in flight, occupancy and work
+        for (const long long P : {4096ll, 81920ll}) { // one workgroup per CU alone; one full round at five waves per SIMD
+            run<16, 1, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 2, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 3, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 4, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 2, 64, 5>(d, P, S, d_out, "u16  ");
+            run<16, 3, 64, 5>(d, P, S, d_out, "u16  ");
+        }
+        for (const long long P : {100000ll, 327680ll}) {
+            run<16, 1, 0, 4>(d, P, S, d_out, "u16  ");
+            run<16, 2, 0, 4>(d, P, S, d_out, "u16  ");
+            run<16, 1, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 2, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 3, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 4, 0, 5>(d, P, S, d_out, "u16  ");
+            run<16, 2, 0, 8>(d, P, S, d_out, "u16  ");
+            run<16, 4, 0, 8>(d, P, S, d_out, "u16  ");
+            run<16, 2, 64, 5>(d, P, S, d_out, "u16  ");
+            run<16, 3, 64, 5>(d, P, S, d_out, "u16  ");
+            run<16, 2, 96, 5>(d, P, S, d_out, "u16  ");
+            run<16, 3, 96, 5>(d, P, S, d_out, "u16  ");
+            run<16, 3, 128, 5>(d, P, S, d_out, "u16  ");
+        }
+        hipFree(d); hipFree(d_out);
+        return 0;
+    }
     for (int pass = 0; pass < 3; ++pass) {
         if (pass == 1) { hipMemset(d, 1, bytes); printf("-- constant data (every byte 1)\n"); }
         if (pass == 2) { // count-like data: small 24-bit numbers
