@@ -1122,7 +1122,6 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
     // EE:1595, EE:1251; an absent record has fw[0] = INT32_MIN, so its FW is negative and fails by itself (one compare feeds the
     // wave mask below directly; with "present &&" in front the mask takes a v_cndmask / v_cmp round trip per row)
     const unsigned long long covmask = __builtin_amdgcn_sicmp(min(FW, BW), cov, 39 /*sge*/);
-    const bool covok = __builtin_amdgcn_inverse_ballot_w64(covmask);
     a.nrec_bad += present ? 1u : 0u;               // EE:1659
     if (covmask == 0) return;
     // RD < 2^19 for uint16 records: never beyond FAST_COUNT_LIMIT; the bit stays for the records-per-lane check
@@ -1131,30 +1130,42 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
     const int lim_fw = ampli_af_limit_f32(fFW), lim_bw = ampli_af_limit_f32(fBW), lim_rd = ampli_af_limit_f32(fRD);
     const double prod_fw = (double)(fFW * C); // EE:1597
     const double prod_bw = (double)(fBW * C); // EE:1599
+    // All wave masks of the row first, then ONE test for the rare first-record block, then the updates as straight-line code:
+    // four separate "rare?" branches per row cut the row into pieces the scheduler cannot move work across, and a wave that has
+    // its SIMD to itself (the partly filled last round of a launch) is bound by exactly that chain.
+    int x[4];
+    unsigned long long thrmask[4], candmask[4], anyfirst = 0;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        if (covok && fw[nt] <= lim_fw && bw[nt] <= lim_bw) { // EE:1595
+        x[nt] = fw[nt] + bw[nt];
+        thrmask[nt] = __builtin_amdgcn_sicmp(fw[nt], lim_fw, 41 /*sle*/) & __builtin_amdgcn_sicmp(bw[nt], lim_bw, 41 /*sle*/) & covmask; // EE:1595
+        // EE:1251: float(X)/float(RD) <= 0.05.  The Germ_Max state machine of EE:1229-1271 in wave masks: zmask = lanes that have not
+        // met their first qualifying record, lmask = lanes that have met a later one (all a reader ever asks of the count)
+        candmask[nt] = __builtin_amdgcn_uicmp((unsigned)x[nt], (unsigned)lim_rd, 37 /*ule*/) & covmask;
+        anyfirst |= candmask[nt] & a.zmask[nt];
+    }
+    if (__builtin_expect(anyfirst != 0, 0)) { // rare: in steady state every passing lane already holds its first record
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const unsigned long long firstmask = candmask[nt] & a.zmask[nt];
+            if (__builtin_amdgcn_inverse_ballot_w64(firstmask)) a.gfa[nt] = (float)x[nt] / fRD; // EE:1229-1232
+            a.zmask[nt] &= ~firstmask;
+            candmask[nt] &= ~firstmask;
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        if (__builtin_amdgcn_inverse_ballot_w64(thrmask[nt])) {
             a.sx[0][nt] += fw[nt]; a.sd[0][nt] += FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
             a.sx[1][nt] += bw[nt]; a.sd[1][nt] += BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
             if (nt < 2) a.cnt01 += nt == 0 ? 1u : 65536u;                     // EE:1606
             else a.cnt23 += nt == 2 ? 1u : 65536u;
         }
-        const int x = fw[nt] + bw[nt];
-        // EE:1251: float(X)/float(RD) <= 0.05.  The Germ_Max state machine of EE:1229-1271 in wave masks: zmask = lanes that have not
-        // met their first qualifying record, lmask = lanes that have met a later one (all a reader ever asks of the count)
-        const unsigned long long passmask = __builtin_amdgcn_uicmp((unsigned)x, (unsigned)lim_rd, 37 /*ule*/) & covmask;
-        unsigned long long candmask = passmask;
-        const unsigned long long firstmask = passmask & a.zmask[nt];
-        if (firstmask) { // rare: in steady state every passing lane already holds its first record
-            if (__builtin_amdgcn_inverse_ballot_w64(firstmask)) a.gfa[nt] = (float)x / fRD; // EE:1229-1232
-            a.zmask[nt] &= ~firstmask;
-            candmask &= ~firstmask;
-        }
-        a.lmask[nt] |= candmask;
+        a.lmask[nt] |= candmask[nt];
         // EE:1266 by cross-multiplication, ties keep the value
-        const unsigned long long gtmask = __builtin_amdgcn_uicmpl(mul24x24_pair(x, a.gbd[nt]), mul24x24_pair(a.gbx[nt], RD), 34 /*ugt*/);
-        const bool better = __builtin_amdgcn_inverse_ballot_w64(candmask & gtmask);
-        a.gbx[nt] = better ? x : a.gbx[nt];
+        const unsigned long long gtmask = __builtin_amdgcn_uicmpl(mul24x24_pair(x[nt], a.gbd[nt]), mul24x24_pair(a.gbx[nt], RD), 34 /*ugt*/);
+        const bool better = __builtin_amdgcn_inverse_ballot_w64(candmask[nt] & gtmask);
+        a.gbx[nt] = better ? x[nt] : a.gbx[nt];
         a.gbd[nt] = better ? RD : a.gbd[nt];
     }
 }
