@@ -178,6 +178,13 @@ int main(int argc, char **argv)
         run<24, 4, 32, 8>(d, P, 96, d_out, "S=96 ");
         run<24, 1, 0, 8>(d, P, 256, d_out, "S=256");
         run<24, 1, 32, 8>(d, P, 256, d_out, "S=256");
+        // round 4: the same with 16-byte records (what config 3 uploads), seven waves per SIMD like poisson_stream_kernel
+        run<16, 1, 0, 7>(d, P, 96, d_out, "S=96 ");
+        run<16, 2, 0, 7>(d, P, 96, d_out, "S=96 ");
+        run<16, 4, 0, 7>(d, P, 96, d_out, "S=96 ");
+        run<16, 1, 32, 7>(d, P, 96, d_out, "S=96 ");
+        run<16, 2, 32, 7>(d, P, 96, d_out, "S=96 ");
+        run<16, 2, 64, 7>(d, P, 96, d_out, "S=96 ");
         hipFree(d); hipFree(d_out);
         return 0;
     }
