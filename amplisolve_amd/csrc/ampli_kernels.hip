@@ -1768,10 +1768,51 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
     // the call-list counters are reset here: only the drain kernel, which starts after this one has finished,
     // appends to the list
     if (n_calls && blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) n_calls[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
+    unsigned tile, y;
+    pc_block_map(blockIdx.x, gy, tile, y);
+    const long long r_raw = (long long)tile * 64 + lane;
+    const int t0 = ((int)y * 4 + wave) * rows_per_wave; // this wave's run of rows
+    const int nt_rows = min(rows_per_wave, T - t0);
+    // padding workgroups of the XCD mapping and waves beyond the last row only clear their share of the mask (below)
+    const bool has_rows = (long long)tile * 64 < R && nt_rows > 0;
+    const bool valid = r_raw < R;
+    const long long r = valid ? r_raw : R - 1;
+    // Everything the row loop needs from memory is REQUESTED first -- the position's reference code, its eight thresholds, the
+    // first record -- and only then is the wave's share of the call mask cleared: written the other way round, the loads queue
+    // behind the mask stores (vmcnt counts both, in order) and behind one another (two dependent round trips before row 0).
+    long long p = 0;
+    int ref = 255;
+    float traw[2][4];
+    RawRec<LAY> nx;
+    size_t step = 0;
+    const char *__restrict__ q = nullptr;
+    if (has_rows) {
+        p = r < P ? r : (long long)ext_pos[r - P];
+        // where this position's eight thresholds live: the plane-major table, or the block of the position's slice (one
+        // integer division per lane, done once)
+        const float *__restrict__ tbase = thr;
+        long long tstride = P, tp = p;
+        if (thr_L != 0) {
+            const long long k = p / thr_L;
+            tbase = (const float *)((const char *)thr + (size_t)k * thr_bb + (size_t)thr_L * 32);
+            tstride = thr_L;
+            tp = p - k * thr_L;
+        }
+        step = (size_t)(r < P ? rv.row_stride : rv.ext_stride) * RB; // bytes between consecutive samples
+        q = r < P ? rv.base + ((size_t)t0 * (size_t)rv.row_stride + (size_t)r) * RB
+                  : rv.ext + ((size_t)t0 * (size_t)rv.ext_stride + (size_t)(r - P)) * RB;
+        nx = rec_load_at<LAY>(q);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) traw[st][nt] = tbase[(st * 4 + nt) * tstride + tp];
+        }
+        ref = valid ? (int)ref_code[p] : 255;
+    }
     // The call mask starts as "no call" (the drain ORs bits in).  Every wave of the grid clears an equal, CONTIGUOUS share
     // of the mask's bytes -- whole 128-byte lines, one store instruction per 256 bytes -- rather than the 64 scattered
     // bytes per row that belong to its own records (partial-line writes cost the streaming kernel ~10 % in the loop).
-    // (Clearing when a wave leaves instead of when it starts was measured: no faster.)
+    // (Clearing when a wave leaves instead of when it starts was measured twice: no faster.)
     {
         const size_t m4 = ((size_t)T * (size_t)R + 3) / 4;       // the mask as dwords (the buffer is padded to a multiple of 4)
         const size_t share = (size_t)rows_per_wave * 16;         // dwords per wave: grid waves x share >= m4
@@ -1779,42 +1820,15 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
         const size_t w1 = w0 + share < m4 ? w0 + share : m4;
         for (size_t o = w0 + lane; o < w1; o += 64) ((unsigned *)call_mask)[o] = 0u;
     }
-    unsigned tile, y;
-    pc_block_map(blockIdx.x, gy, tile, y);
-    const long long r_raw = (long long)tile * 64 + lane;
-    if ((long long)tile * 64 >= R) return; // padding workgroups of the XCD mapping
-    const bool valid = r_raw < R;
-    const long long r = valid ? r_raw : R - 1;
-    const long long p = r < P ? r : (long long)ext_pos[r - P];
-    const int t0 = ((int)y * 4 + wave) * rows_per_wave; // this wave's run of rows
-    const int nt_rows = min(rows_per_wave, T - t0);
-    if (nt_rows <= 0) return;
-    const int ref = valid ? (int)ref_code[p] : 255;
-
-    // where this position's eight thresholds live: the plane-major table, or the block of the position's slice (one
-    // integer division per lane, done once)
-    const float *__restrict__ tbase = thr;
-    long long tstride = P, tp = p;
-    if (thr_L != 0) {
-        const long long k = p / thr_L;
-        tbase = (const float *)((const char *)thr + (size_t)k * thr_bb + (size_t)thr_L * 32);
-        tstride = thr_L;
-        tp = p - k * thr_L;
-    }
+    if (!has_rows) return;
     float te[2][4]; // effective error per strand / nucleotide
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            te[st][nt] = ampli_effective_err(tbase[(st * 4 + nt) * tstride + tp]); // VC:887-890
-        }
+        for (int st = 0; st < 2; ++st) te[st][nt] = ampli_effective_err(traw[st][nt]); // VC:887-890
     }
     const unsigned shard = blockIdx.x % AMPLI_CALL_SHARDS;
 
-    const size_t step = (size_t)(r < P ? rv.row_stride : rv.ext_stride) * RB; // bytes between consecutive samples
-    const char *__restrict__ q = r < P ? rv.base + ((size_t)t0 * (size_t)rv.row_stride + (size_t)r) * RB
-                                       : rv.ext + ((size_t)t0 * (size_t)rv.ext_stride + (size_t)(r - P)) * RB;
-    RawRec<LAY> nx = rec_load_at<LAY>(q);
     for (int dt = 0; dt < nt_rows; ++dt) {
         int4 r0v, r1v;
         rec_decode<LAY>(nx, r0v, r1v);
