@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--sustained", type=int, default=2000, help="passes of the sustained-rate block after the timed region (0 = skip)")
     ap.add_argument("--cold-batches", type=int, default=3, help="N = 1: distinct resident batches the cold-HBM block rotates over after the timed region "
                     "(no pass finds its inputs in the Infinity Cache); 0 or 1 = skip")
+    ap.add_argument("--no-split-ranges", dest="split_ranges", action="store_false", help="N = 1: skip the block that repeats the pass with the "
+                    "positions in two ranges on two streams (after the timed region)")
     ap.add_argument("--whole-rounds", type=int, default=4, help="N = 1: after the timed region, time the dominant reduce kernel on a panel of this many "
                     "whole rounds of resident workgroups (what the partly filled last round of the configuration costs); 0 = skip")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the reference's error estimation on ALL normals of config 3 (~6 min on one core)")
@@ -919,6 +921,71 @@ def main():
             raise SystemExit("kernel flags raised in the whole-rounds block")
         del an2, f2
 
+    # The same pass with the panel's positions cut into two tile-aligned ranges, each range on a stream of its own (own context,
+    # own outputs; the inputs are views of the same resident batch): the second range's error_reduce and the first range's
+    # poisson_call fill the thin last round of workgroups that a single launch of config 3 ends with.
+    # Same results, position for position.  Outside the contract's timed region, which stays one stream so that the kernel
+    # durations of `roofline` are those of undisturbed launches; `--ranges 2` is not needed to get this block.
+    two_ranges = None
+    if not multi and lanes is None and args.split_ranges and mode == POISSON_PREFILTER and P >= 4096:
+        cut = ((P + 63) // 64 // 2) * 64
+        relem = {"i32": 8, "u16": 8, "u24": 24}[layout]
+        nv, tv = normals.view(S, P, relem), tumours.view(T, P, relem)
+        parts = []
+        for lo, hi in ((0, cut), (cut, P)):
+            st = torch.cuda.Stream(device=dev_index)
+            with torch.cuda.stream(st):
+                c = Context(dev_index)
+                c.set_record_layout(layout)
+                nrec = c.records(nv[:, lo:hi], layout, S, row_stride=P)
+                trec = c.records(tv[:, lo:hi], layout, T, row_stride=P)
+                rc = ref_code[lo:hi].contiguous()
+                f = c.error_reduce_records(nrec, hi - lo, None, finalize=True)
+                r = c.poisson_call_records(trec, hi - lo, f.thr, rc, 100, capacity=cap)
+            parts.append(dict(c=c, st=st, n=hi - lo, nrec=nrec, trec=trec, rc=rc, f=f, r=r))
+        torch.cuda.synchronize()
+
+        def part_step(q):
+            q["c"].error_reduce_records(q["nrec"], q["n"], None, out=q["f"], finalize=True)
+            q["c"].poisson_call_records(q["trec"], q["n"], q["f"].thr, q["rc"], 100, call_mask=q["r"]["call_mask"], capacity=q["r"]["capacity"],
+                                        calls_buf=q["r"]["calls_buf"], n_calls=q["r"]["n_calls"])
+
+        for _ in range(max(2, args.warmup)):
+            for q in parts:
+                part_step(q)
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream()
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record(cur)
+        for q in parts:
+            q["st"].wait_event(ea)
+        for _ in range(args.steps):
+            for q in parts:
+                part_step(q)
+        for q in parts:
+            cur.wait_stream(q["st"])
+        eb.record(cur)
+        torch.cuda.synchronize()
+        ms2 = ea.elapsed_time(eb) / args.steps
+        # against the single-stream pass over the whole panel (the timed region's own outputs)
+        f1 = ctx.error_estimate(normals, P, 0.002, 100)
+        r1 = ctx.poisson_call(tumours, P, f1.thr, ref_code, 100, mode=mode, capacity=cap)
+        torch.cuda.synchronize()
+        same2 = all(torch.equal(torch.cat([getattr(q["f"], k) for q in parts], dim=-1).view(torch.uint8), getattr(f1, k).view(torch.uint8))
+                    for k in ("rate", "thr", "code", "germ_present"))
+        same2 = same2 and torch.equal(torch.cat([q["r"]["call_mask"] for q in parts], dim=1), r1["call_mask"])
+        same2 = same2 and sum(q["c"].n_calls_total(q["r"]) for q in parts) == ctx.n_calls_total(r1)
+        bad2 = any(q["c"].flags(clear=True) != 0 for q in parts)
+        two_ranges = {"positions": [cut, P - cut], "streams": 2, "steps": args.steps, "ms_per_step": ms2, "value": (P * S + P * T) / (ms2 * 1e-3),
+                      "same_outputs": bool(same2) and not bad2,
+                      "note": "the pass of the timed region with its positions in two ranges on two streams (kernels of one range fill the other's "
+                              "partly filled rounds); events around the whole run on a parent stream; outputs compared with the single-stream pass"}
+        if bad2:
+            raise SystemExit("kernel flags raised in the two-ranges block")
+        for q in parts:
+            q["c"].close()
+        del parts, f1, r1
+
     others = []
     for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and not multi and lanes is None]:
         # the same workload in the other record layouts, outside the timed region, for comparison
@@ -1065,6 +1132,8 @@ def main():
             out["cold_hbm"] = cold
         if whole_rounds:
             out["roofline_whole_rounds"] = whole_rounds
+        if two_ranges:
+            out["two_ranges"] = two_ranges
         if multi:
             out["communication"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "merge": args.merge,
                                     "local_step_ms": t_local_ms, "exposed_ms_per_step": max(0.0, ms_per_step - t_local_ms),

@@ -273,3 +273,47 @@ def test_sliced_merge_through_the_compact_kernel(ctx16, P, S, n, slim):
         ctx16.set_reduce_compact(True)
         ctx16.set_tuning(0)
         ctx16.set_slice_format(False)
+
+
+@pytest.mark.parametrize("P,S,T,cut", [(5000, 24, 6, 2496), (20000, 256, 8, 9984), (130, 9, 3, 64)])
+def test_position_ranges_on_two_streams_equal_the_single_pass(ctx16, P, S, T, cut):
+    """bench.py's `two_ranges` block: the panel's positions cut into two tile-aligned ranges, each with its own context, stream and
+    outputs, reading VIEWS of the same resident arrays (row stride = the whole panel): error table and call mask of the two
+    ranges side by side are the single pass's, bit for bit -- and both are the oracle's."""
+    import torch
+
+    from amplisolve_amd import Context
+
+    lay = ctx16.layout_name
+    recs, trecs = synth_recs(P, S), synth_recs(P, T, tumour=True)
+    rng = np.random.default_rng(P + S + T)
+    e = edge_case_recs(P, S, rng)
+    pick = rng.random((S, P)) < 0.2
+    recs[pick] = e[pick]
+    ref = synth_ref(P)
+    nd, td, rd = to16(ctx16, recs), to16(ctx16, trecs), _t(ref)
+    relem = nd.shape[-1]
+    want = orc.error_finalize(orc.error_reduce(recs, P, 0.002, 100))
+    whole = ctx16.error_estimate(nd, P, 0.002, 100)
+    assert_final_equal(whole, want)
+    wres = ctx16.poisson_call(td, P, whole.thr, rd, 100, capacity=1 << 16)
+    parts = []
+    for lo, hi in ((0, cut), (cut, P)):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            c = Context(0)
+            c.set_record_layout(lay)
+            nrec = c.records(nd.view(S, P, relem)[:, lo:hi], lay, S, row_stride=P)
+            trec = c.records(td.view(T, P, relem)[:, lo:hi], lay, T, row_stride=P)
+            f = c.error_reduce_records(nrec, hi - lo, None, finalize=True)
+            r = c.poisson_call_records(trec, hi - lo, f.thr, rd[lo:hi].contiguous(), 100, capacity=1 << 16)
+        parts.append((c, f, r))
+    torch.cuda.synchronize()
+    for k in ("rate", "thr", "code", "germ_present", "germ_val"):
+        got = torch.cat([getattr(f, k) for _, f, _ in parts], dim=-1)
+        assert torch.equal(got.view(torch.uint8), getattr(whole, k).view(torch.uint8)), k
+    assert torch.equal(torch.cat([r["call_mask"] for _, _, r in parts], dim=1), wres["call_mask"])
+    assert sum(c.n_calls_total(r) for c, _, r in parts) == ctx16.n_calls_total(wres)
+    for c, _, _ in parts:
+        assert c.flags() == 0
+        c.close()

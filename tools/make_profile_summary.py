@@ -42,7 +42,7 @@ h = hashlib.sha256()
 for f in ("ampli_kernels.hip", "ampli_math.h"):
     h.update(open(os.path.join("amplisolve_amd", "csrc", f), "rb").read())
 # bench.py only quotes these counters while the kernel source is the one they were collected on
-json.dump({"kernel_source_sha256": h.hexdigest(), "command": "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0 --whole-rounds 0",
+json.dump({"kernel_source_sha256": h.hexdigest(), "command": "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0 --whole-rounds 0 --no-split-ranges",
            "kernels": out}, open(f"{dst}/pmc_summary.json", "w"), indent=1, sort_keys=True)
 for name in ("bench_default.log", "bench_under_trace.log"):
     p = f"{src}/{name}"

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/pmc_extra
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0 --whole-rounds 0"
+CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0 --whole-rounds 0 --no-split-ranges"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $OUT/a -- $CMD > $OUT/a.log 2>&1 || { tail -5 $OUT/a.log; }
 timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_IFETCH SQ_INST_LEVEL_VMEM SQ_WAVES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/b -- $CMD > $OUT/b.log 2>&1 || { tail -5 $OUT/b.log; }
 python3 - <<PY
