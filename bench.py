@@ -893,33 +893,37 @@ def main():
     # round costs (tools/sweep_tiles.py).  Outside the timed region; N = 1 only.
     whole_rounds = None
     if not multi and lanes is None and args.whole_rounds > 0:
-        kname = ctx.last_reduce_kernel()
-        # workgroups a CU holds: 96 VGPRs -> five waves per SIMD (compact kernel), 120 -> four (general); one wave of each of a CU's SIMDs per workgroup
-        per_round = torch.cuda.get_device_properties(dev_index).multi_processor_count * (5 if kname == "error_reduce_u16_kernel" else 4)
-        P2 = per_round * args.whole_rounds * 64
-        an2 = ctx.synth_fill(P2, S, seed=SEED, depth=depth)
-        if layout != "i32":
-            an2 = ctx.pack(an2, layout)[0]
-        f2 = ctx.error_estimate(an2, P2, 0.002, 100)
-        for _ in range(2):
-            ctx.error_estimate(an2, P2, 0.002, 100, out=f2)
-        ea, eb = ctx.event(), ctx.event()
-        ctx.record(ea)
-        for _ in range(10):
-            ctx.error_estimate(an2, P2, 0.002, 100, out=f2)
-        ctx.record(eb)
-        torch.cuda.synchronize()
-        t2 = ctx.elapsed_ms(ea, eb) / 10
-        b2 = rec_bytes * P2 * S + 88 * P2
-        whole_rounds = {"kernel": ctx.last_reduce_kernel(), "positions": P2, "tiles": P2 // 64, "resident_workgroups": per_round,
-                        "rounds_of_workgroups": args.whole_rounds, "config_rounds_of_workgroups": ((P + 63) // 64) / per_round,
-                        "avg_ms": t2, "algorithmic_bytes": b2, "achieved": b2 / (t2 * 1e-3) / 1e9, "unit": "GB/s",
-                        "frac": b2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "note": "the dominant kernel on a panel that is a whole number of rounds of resident workgroups (same samples per position, "
-                                "same layout), 10 launches back to back, HIP events; roofline.frac is the configuration's own launch"}
-        if ctx.flags(clear=True) != 0:
-            raise SystemExit("kernel flags raised in the whole-rounds block")
-        del an2, f2
+        try:
+            kname = ctx.last_reduce_kernel()
+            # workgroups a CU holds: 96 VGPRs -> five waves per SIMD (compact kernel), 120 -> four (general); one wave of each of a CU's SIMDs per workgroup
+            per_round = torch.cuda.get_device_properties(dev_index).multi_processor_count * (5 if kname == "error_reduce_u16_kernel" else 4)
+            P2 = per_round * args.whole_rounds * 64
+            an2 = ctx.synth_fill(P2, S, seed=SEED, depth=depth)
+            if layout != "i32":
+                an2 = ctx.pack(an2, layout)[0]
+            f2 = ctx.error_estimate(an2, P2, 0.002, 100)
+            for _ in range(2):
+                ctx.error_estimate(an2, P2, 0.002, 100, out=f2)
+            ea, eb = ctx.event(), ctx.event()
+            ctx.record(ea)
+            for _ in range(10):
+                ctx.error_estimate(an2, P2, 0.002, 100, out=f2)
+            ctx.record(eb)
+            torch.cuda.synchronize()
+            t2 = ctx.elapsed_ms(ea, eb) / 10
+            b2 = rec_bytes * P2 * S + 88 * P2
+            whole_rounds = {"kernel": ctx.last_reduce_kernel(), "positions": P2, "tiles": P2 // 64, "resident_workgroups": per_round,
+                            "rounds_of_workgroups": args.whole_rounds, "config_rounds_of_workgroups": ((P + 63) // 64) / per_round,
+                            "avg_ms": t2, "algorithmic_bytes": b2, "achieved": b2 / (t2 * 1e-3) / 1e9, "unit": "GB/s",
+                            "frac": b2 / (t2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "the dominant kernel on a panel that is a whole number of rounds of resident workgroups (same samples per position, "
+                                    "same layout), 10 launches back to back, HIP events; roofline.frac is the configuration's own launch"}
+            if ctx.flags(clear=True) != 0:
+                raise SystemExit("kernel flags raised in the whole-rounds block")
+            del an2, f2
+        except (Exception, SystemExit) as exc:  # an extra block must not cost the run its line: the failure is reported in its place
+            whole_rounds = {"error": f"{type(exc).__name__}: {exc}"}
+            print(f"bench.py: the whole_rounds block failed: {exc}", file=sys.stderr)
 
     # The same pass with the panel's positions cut into two tile-aligned ranges, each range on a stream of its own (own context,
     # own outputs; the inputs are views of the same resident batch): the second range's error_reduce and the first range's
@@ -928,63 +932,67 @@ def main():
     # durations of `roofline` are those of undisturbed launches; `--ranges 2` is not needed to get this block.
     two_ranges = None
     if not multi and lanes is None and args.split_ranges and mode == POISSON_PREFILTER and P >= 4096:
-        cut = ((P + 63) // 64 // 2) * 64
-        relem = {"i32": 8, "u16": 8, "u24": 24}[layout]
-        nv, tv = normals.view(S, P, relem), tumours.view(T, P, relem)
-        parts = []
-        for lo, hi in ((0, cut), (cut, P)):
-            st = torch.cuda.Stream(device=dev_index)
-            with torch.cuda.stream(st):
-                c = Context(dev_index)
-                c.set_record_layout(layout)
-                nrec = c.records(nv[:, lo:hi], layout, S, row_stride=P)
-                trec = c.records(tv[:, lo:hi], layout, T, row_stride=P)
-                rc = ref_code[lo:hi].contiguous()
-                f = c.error_reduce_records(nrec, hi - lo, None, finalize=True)
-                r = c.poisson_call_records(trec, hi - lo, f.thr, rc, 100, capacity=cap)
-            parts.append(dict(c=c, st=st, n=hi - lo, nrec=nrec, trec=trec, rc=rc, f=f, r=r))
-        torch.cuda.synchronize()
+        try:
+            cut = ((P + 63) // 64 // 2) * 64
+            relem = {"i32": 8, "u16": 8, "u24": 24}[layout]
+            nv, tv = normals.view(S, P, relem), tumours.view(T, P, relem)
+            parts = []
+            for lo, hi in ((0, cut), (cut, P)):
+                st = torch.cuda.Stream(device=dev_index)
+                with torch.cuda.stream(st):
+                    c = Context(dev_index)
+                    c.set_record_layout(layout)
+                    nrec = c.records(nv[:, lo:hi], layout, S, row_stride=P)
+                    trec = c.records(tv[:, lo:hi], layout, T, row_stride=P)
+                    rc = ref_code[lo:hi].contiguous()
+                    f = c.error_reduce_records(nrec, hi - lo, None, finalize=True)
+                    r = c.poisson_call_records(trec, hi - lo, f.thr, rc, 100, capacity=cap)
+                parts.append(dict(c=c, st=st, n=hi - lo, nrec=nrec, trec=trec, rc=rc, f=f, r=r))
+            torch.cuda.synchronize()
 
-        def part_step(q):
-            q["c"].error_reduce_records(q["nrec"], q["n"], None, out=q["f"], finalize=True)
-            q["c"].poisson_call_records(q["trec"], q["n"], q["f"].thr, q["rc"], 100, call_mask=q["r"]["call_mask"], capacity=q["r"]["capacity"],
-                                        calls_buf=q["r"]["calls_buf"], n_calls=q["r"]["n_calls"])
+            def part_step(q):
+                q["c"].error_reduce_records(q["nrec"], q["n"], None, out=q["f"], finalize=True)
+                q["c"].poisson_call_records(q["trec"], q["n"], q["f"].thr, q["rc"], 100, call_mask=q["r"]["call_mask"], capacity=q["r"]["capacity"],
+                                            calls_buf=q["r"]["calls_buf"], n_calls=q["r"]["n_calls"])
 
-        for _ in range(max(2, args.warmup)):
+            for _ in range(max(2, args.warmup)):
+                for q in parts:
+                    part_step(q)
+            torch.cuda.synchronize()
+            cur = torch.cuda.current_stream()
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(cur)
             for q in parts:
-                part_step(q)
-        torch.cuda.synchronize()
-        cur = torch.cuda.current_stream()
-        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ea.record(cur)
-        for q in parts:
-            q["st"].wait_event(ea)
-        for _ in range(args.steps):
+                q["st"].wait_event(ea)
+            for _ in range(args.steps):
+                for q in parts:
+                    part_step(q)
             for q in parts:
-                part_step(q)
-        for q in parts:
-            cur.wait_stream(q["st"])
-        eb.record(cur)
-        torch.cuda.synchronize()
-        ms2 = ea.elapsed_time(eb) / args.steps
-        # against the single-stream pass over the whole panel (the timed region's own outputs)
-        f1 = ctx.error_estimate(normals, P, 0.002, 100)
-        r1 = ctx.poisson_call(tumours, P, f1.thr, ref_code, 100, mode=mode, capacity=cap)
-        torch.cuda.synchronize()
-        same2 = all(torch.equal(torch.cat([getattr(q["f"], k) for q in parts], dim=-1).view(torch.uint8), getattr(f1, k).view(torch.uint8))
-                    for k in ("rate", "thr", "code", "germ_present"))
-        same2 = same2 and torch.equal(torch.cat([q["r"]["call_mask"] for q in parts], dim=1), r1["call_mask"])
-        same2 = same2 and sum(q["c"].n_calls_total(q["r"]) for q in parts) == ctx.n_calls_total(r1)
-        bad2 = any(q["c"].flags(clear=True) != 0 for q in parts)
-        two_ranges = {"positions": [cut, P - cut], "streams": 2, "steps": args.steps, "ms_per_step": ms2, "value": (P * S + P * T) / (ms2 * 1e-3),
-                      "same_outputs": bool(same2) and not bad2,
-                      "note": "the pass of the timed region with its positions in two ranges on two streams (kernels of one range fill the other's "
-                              "partly filled rounds); events around the whole run on a parent stream; outputs compared with the single-stream pass"}
-        if bad2:
-            raise SystemExit("kernel flags raised in the two-ranges block")
-        for q in parts:
-            q["c"].close()
-        del parts, f1, r1
+                cur.wait_stream(q["st"])
+            eb.record(cur)
+            torch.cuda.synchronize()
+            ms2 = ea.elapsed_time(eb) / args.steps
+            # against the single-stream pass over the whole panel (the timed region's own outputs)
+            f1 = ctx.error_estimate(normals, P, 0.002, 100)
+            r1 = ctx.poisson_call(tumours, P, f1.thr, ref_code, 100, mode=mode, capacity=cap)
+            torch.cuda.synchronize()
+            same2 = all(torch.equal(torch.cat([getattr(q["f"], k) for q in parts], dim=-1).view(torch.uint8), getattr(f1, k).view(torch.uint8))
+                        for k in ("rate", "thr", "code", "germ_present"))
+            same2 = same2 and torch.equal(torch.cat([q["r"]["call_mask"] for q in parts], dim=1), r1["call_mask"])
+            same2 = same2 and sum(q["c"].n_calls_total(q["r"]) for q in parts) == ctx.n_calls_total(r1)
+            bad2 = any(q["c"].flags(clear=True) != 0 for q in parts)
+            two_ranges = {"positions": [cut, P - cut], "streams": 2, "steps": args.steps, "ms_per_step": ms2, "value": (P * S + P * T) / (ms2 * 1e-3),
+                          "same_outputs": bool(same2) and not bad2,
+                          "note": "the pass of the timed region with its positions in two ranges on two streams (kernels of one range fill the other's "
+                                  "partly filled rounds); events around the whole run on a parent stream; outputs compared with the single-stream pass"}
+            if bad2:
+                raise SystemExit("kernel flags raised in the two-ranges block")
+            for q in parts:
+                q["c"].close()
+            del parts, f1, r1
+        except (Exception, SystemExit) as exc:  # an extra block must not cost the run its line: the failure is reported in its place
+            two_ranges = {"error": f"{type(exc).__name__}: {exc}"}
+            print(f"bench.py: the two_ranges block failed: {exc}", file=sys.stderr)
 
     others = []
     for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and not multi and lanes is None]:
