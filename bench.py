@@ -502,6 +502,9 @@ def main():
                   TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack))
 
     ev = [[ctx.event() for _ in range(4)] for _ in range(args.steps)]
+    if not multi:  # nothing happens between the end of the reduce and the start of the call on one GPU: one marker serves as both
+        for e in ev:
+            e[2] = e[1]
     ev_steps = [i for i in range(args.steps) if i % max(1, args.event_every) == 0]
 
     # two error tables, used alternately: with the asynchronous drain the survivors of batch i are still being scored
@@ -542,7 +545,7 @@ def main():
             return
         elif multi:  # finalize straight from the all-reduced sums + gathered germ-max regions
             fins[i & 1] = fin = ctx.error_finalize_merged(P, merger.packed[slot], merger.gathered[slot], world, 0.002, 100, out=fins[i & 1])
-        if timed:
+        if timed and multi:
             ctx.record(ev[i][2])
         ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
                          calls_buf=calls_buf, n_calls=n_calls)
