@@ -46,3 +46,27 @@ def test_rccl_calls_of_the_sliced_merge_on_a_size_one_communicator():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "nccl selftest ok" in r.stdout
+
+
+def test_bench_line_at_one_gpu_has_the_contract_fields():
+    """`python bench.py` (N = 1) on the small configuration: ONE JSON line with the contract's fields, the roofline of the dominant
+    kernel, and the self-checks of the blocks behind the timed region (layouts, position ranges on two streams) all true."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-e2e",
+           "--sustained", "40", "--cold-batches", "2", "--whole-rounds", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "kernels"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "none" and d["data"].startswith("synthetic") and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - (d["config"]["positions"] * (d["config"]["normals_total"] + d["config"]["tumours_total"])) / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "traffic" in rf and 0 < rf["frac"] < 1
+    assert all(x["same_outputs"] for x in d["other_record_layouts"])
+    assert d["two_ranges"]["same_outputs"] is True and d["roofline_whole_rounds"]["frac"] > 0
+    assert d["sustained"]["passes"] == 40 and d["cold_hbm"]["batches"] == 2
