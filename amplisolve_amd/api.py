@@ -262,17 +262,26 @@ class Context:
         return r
 
     def error_reduce_records(self, rec: Records, P: int, acc: Acc | None, C_value: float = 0.002, cov: int = 100, first_sample: int = 0,
-                             accumulate: bool = False, out: ErrorTable | None = None, finalize: bool = False):
-        """One chunk of a cohort into `acc` (accumulate: acc (+) chunk); finalize: also the error table of the merged state."""
+                             accumulate: bool = False, out: ErrorTable | None = None, finalize: bool = False, summary: bool = False):
+        """One chunk of a cohort into `acc` (accumulate: acc (+) chunk); finalize: also the error table of the merged state.
+        summary: `acc` is streaming state only (AMPLI_REDUCE_SUMMARY: gm_n may saturate at two, gm_first may read -1), which lets
+        the compact-state kernel carry it."""
         if finalize and out is None:
             out = self._new_error_table(P)
         o = out if finalize else None
         self._check(self.lib.ampli_error_reduce_records(self.h, C.byref(rec), P, first_sample, C_value, cov,
-                                                        C.byref(acc.struct) if acc is not None else None, int(accumulate),
+                                                        C.byref(acc.struct) if acc is not None else None, int(bool(accumulate)) | (2 if summary else 0),
                                                         _ptr(o.rate) if o else None, _ptr(o.code) if o else None, _ptr(o.thr) if o else None,
                                                         _ptr(o.germ_val) if o else None, _ptr(o.germ_present) if o else None,
                                                         _ptr(o.flags) if o else None))
         return out
+
+    def error_reduce_records_sliced(self, rec: Records, P: int, acc: Acc | None, n_slices: int, sums, gm, C_value: float = 0.002, cov: int = 100,
+                                    first_sample: int = 0, accumulate: bool = False, summary: bool = True):
+        """The last chunk of a shard's streamed cohort: acc (+) chunk straight into the slice-major exchange buffers."""
+        self._check(self.lib.ampli_error_reduce_records_sliced(self.h, C.byref(rec), P, first_sample, C_value, cov,
+                                                               C.byref(acc.struct) if acc is not None else None,
+                                                               int(bool(accumulate)) | (2 if summary else 0), n_slices, _ptr(sums), _ptr(gm)))
 
     def poisson_call_records(self, rec: Records, P: int, thr, ref_code, cov: int = 100, mode: int = POISSON_PREFILTER,
                              call_mask=None, capacity: int = 0, calls_buf=None, n_calls=None):

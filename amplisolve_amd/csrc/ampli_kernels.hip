@@ -636,6 +636,7 @@ struct FinOut {
     int *sl_flags;       //  (slim) the context's flag word: AMPLI_FLAG_SLICE_RANGE when a value does not fit its share of a field
     int accumulate;      // the table already holds the state of the EARLIER samples: result = table (+) this launch
                          //  (streamed cohorts: one launch per uploaded chunk of samples, in visit order)
+    int summary;         // host side only: the caller takes the table as streaming state (AMPLI_REDUCE_SUMMARY), so the compact kernel may write it
 };
 
 __device__ __forceinline__ void lane_acc_store_packed(double *__restrict__ pk, const long long P, const long long p, const LaneAcc &a)
@@ -975,14 +976,21 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
     const RecView rv, const long long P, const long long E, const unsigned *__restrict__ dup_off,
     const int S, const int first_sample, const int chunk_len, const float C, const int cov, char *out_base,
     const size_t part_stride, const size_t o0, const size_t o1, const size_t o2, const size_t o3, const size_t o4,
-    const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags, const FinOut fin)
+    const size_t o5, const size_t o6, const size_t o7, int *__restrict__ flags, const FinOut fin, const unsigned *__restrict__ tile_list)
 {
     constexpr int W = 64 / G; // positions per wave
     __shared__ RedShared sh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform, and the compiler may know it
     const int group = lane / W;
-    const long long p_raw = (long long)blockIdx.x * W + (lane % W);
+    // tile_list (G == 1 only): the tiles this launch serves -- those the compact kernel left because they hold a position listed
+    // more than once (dup_tiles_kernel); the grid is an upper bound of their number
+    unsigned tile = blockIdx.x;
+    if (tile_list) {
+        if (blockIdx.x >= tile_list[0]) return;
+        tile = tile_list[1 + blockIdx.x];
+    }
+    const long long p_raw = (long long)tile * W + (lane % W);
     const bool valid = p_raw < P;
     const long long p = valid ? p_raw : P - 1; // clamp: out-of-range lanes re-read the last position, never store
     const int chunk = (blockIdx.y * RED_WAVES + wave) * G + group;
@@ -1074,9 +1082,9 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
                 } else {
                     lane_acc_store(t, P, p_raw, a);
                 }
-            } else if (fin.slice_len) { // multi-GPU shard, sliced exchange: no table at all
-                lane_acc_store_sliced(fin, p_raw, a);
             }
+            // multi-GPU shard, sliced exchange: no table at all, or (last chunk of a streamed shard) the table's state (+) this chunk
+            if (fin.slice_len) lane_acc_store_sliced(fin, p_raw, a);
             // fused epilogue (single split only): the merged state is in registers, finalize it here and spare the
             // table round trip through HBM plus a launch
             if (fin.rate) finalize_lane(a, P, p_raw, C, cov, fin);
@@ -1170,6 +1178,16 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
     }
 }
 
+// tiles (64 positions) that hold a position listed more than once: list[0] = their number, list[1..] = their indices, any order.
+// dup_off is a prefix sum, so a tile holds extras iff dup_off differs at its two ends.
+__global__ __launch_bounds__(256) void dup_tiles_kernel(const unsigned *__restrict__ dup_off, const long long P, unsigned *__restrict__ list)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long lo = t * 64, hi = lo + 64 < P ? lo + 64 : P;
+    if (lo >= P) return;
+    if (dup_off[hi] != dup_off[lo]) list[1 + atomicAdd(&list[0], 1u)] = (unsigned)t;
+}
+
 struct Red16Shared {
     double snt[2][8][64];
     long long srd[2][8][64];
@@ -1224,16 +1242,77 @@ __device__ __forceinline__ void part16_merge(Part16 &L, const Red16Shared &sh, c
     L.nrec += sh.ints[slot][4][lane];
 }
 
-__global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView rv, const long long P, const int S, const int chunk_len,
-                                                                  const float C, const int cov, int *__restrict__ flags, const FinOut fin)
+// the state of the EARLIER samples out of the accumulator table (a streamed cohort: one launch per uploaded chunk, in visit order):
+// a = table (+) a, lane_acc_merge with the table on the left, field by field out of HBM.  Returns a bit per nucleotide whose
+// first qualifying record already lies in the table (its gm_first entry then stays what it is).
+__device__ __forceinline__ unsigned part16_carry_in(Part16 &a, const AccPtrs &t, const long long P, const long long p)
+{
+    unsigned had = 0;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        a.snt[0][nt] += t.snt[(0 * 4 + nt) * P + p]; a.snt[1][nt] += t.snt[(1 * 4 + nt) * P + p];
+        a.srd[0][nt] += t.srd[(0 * 4 + nt) * P + p]; a.srd[1][nt] += t.srd[(1 * 4 + nt) * P + p];
+        a.cnt[nt] += t.cnt[nt * P + p];
+        const int ln = t.gm_n[nt * P + p];
+        if (ln != 0) {
+            const float lf = t.gm_first_af[nt * P + p], lr = t.gm_rest[nt * P + p];
+            float m = lr;
+            if (a.gm_n[nt] != 0) { // EE:1266 over the later records: the table's rest, this chunk's first, this chunk's rest
+                if (m <= a.gm_first_af[nt]) m = a.gm_first_af[nt];
+                if (m <= a.gm_rest[nt]) m = a.gm_rest[nt];
+            }
+            a.gm_rest[nt] = m;
+            a.gm_first_af[nt] = lf;
+            a.gm_n[nt] += ln;
+            had |= 1u << nt;
+        }
+        // one nucleotide's loads at a time: hoisted together they need more registers than the row loop does (the kernel sits at
+        // exactly 96 VGPRs = five waves per SIMD; the first build of this epilogue spilled 12 bytes per lane for them)
+        asm volatile("" ::: "memory");
+    }
+    a.nrec += t.nrec[p];
+    return had;
+}
+
+// The table as this kernel leaves it is a SUMMARY of the Germ_Max bookkeeping (AMPLI_REDUCE_SUMMARY): gm_n counts a chunk's
+// qualifying records as none / one / two-or-more -- all any merge, the sliced store or finalize ever ask of it -- and the sample
+// index of a first record met here reads -1 (unknown), as after a gathered merge.  Every other plane is exact.
+__device__ __forceinline__ void part16_store(const AccPtrs &t, const long long P, const long long p, const Part16 &a, const unsigned had)
+{
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        t.snt[(0 * 4 + nt) * P + p] = a.snt[0][nt]; t.snt[(1 * 4 + nt) * P + p] = a.snt[1][nt];
+        t.srd[(0 * 4 + nt) * P + p] = a.srd[0][nt]; t.srd[(1 * 4 + nt) * P + p] = a.srd[1][nt];
+        t.cnt[nt * P + p] = a.cnt[nt];
+        t.gm_n[nt * P + p] = a.gm_n[nt];
+        t.gm_first_af[nt * P + p] = a.gm_first_af[nt];
+        t.gm_rest[nt * P + p] = a.gm_rest[nt];
+        if (!((had >> nt) & 1)) t.gm_first[nt * P + p] = a.gm_n[nt] ? -1 : 0x7fffffff;
+    }
+    t.nrec[p] = a.nrec;
+}
+
+// positions [p_lo, p_hi) of a panel of P (P = the stride of every per-position plane); tile b = positions p_lo + 64 b ...
+// DUP: the cohort lists positions more than once (E > 0, overlapping amplicons: every line is a record, EE:1555 equal_range over
+// all lines of a key, and EE:1251-1271 is order-dependent: primary record, then the extras in file order, sample after sample).
+// A tile that holds such a position is not this kernel's: its workgroup leaves at once and error_reduce_kernel takes the tile
+// from dup_tiles_kernel's list (same epilogue forms, same outputs).  Measured alternative, round 5: the sample-by-sample walk of
+// such tiles inside this kernel -- correct, but the second loop costs the first one two registers it does not have (spill
+// stores inside the row loop of EVERY tile of the cohort).
+// TAB: the launch reads and / or writes the accumulator table (a streamed cohort's chunks); without it the epilogue is the headline's.
+template <bool DUP, bool TAB>
+__global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView rv, const long long P, const long long p_lo, const long long p_hi,
+                                                                  const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
+                                                                  const float C, const int cov, int *__restrict__ flags, const AccPtrs tab,
+                                                                  const FinOut fin)
 {
     __shared__ Red16Shared sh;
     constexpr int RB = 16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long p_raw = (long long)blockIdx.x * 64 + lane;
-    const bool valid = p_raw < P;
-    const long long p = valid ? p_raw : P - 1; // clamp: out-of-range lanes re-read the last position, never store
+    const long long p_raw = p_lo + (long long)blockIdx.x * 64 + lane;
+    const bool valid = p_raw < p_hi;
+    const long long p = valid ? p_raw : p_hi - 1; // clamp: out-of-range lanes re-read the last position, never store
     const int s0 = min(S, wave * chunk_len);
     const int s1 = min(S, s0 + chunk_len);
     Fast16 f;
@@ -1246,6 +1325,9 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
     f.nrec_bad = 0u;
     const size_t row_step = (size_t)rv.row_stride * RB;
     const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;
+    if (DUP) { // a tile with a position listed more than once is left to error_reduce_kernel (launched over the list of such tiles)
+        if (__any(dup_off[p + 1] != dup_off[p])) return; // the four waves of a workgroup see the same tile: all leave, before any barrier
+    }
     // Three named register sets in rotation: rows s + 1 and s + 2 are in flight while row s is consumed (s_waitcnt vmcnt(2)).
     // (Written as one row per trip with a "next" record, hipcc copies the freshly loaded record into the loop-carried registers
     // at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none; that form ran
@@ -1305,6 +1387,9 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
     if (wave == 0) {
         part16_merge(a, sh, 0, lane);
         if (valid) {
+            unsigned had = 0;
+            if (TAB && fin.accumulate) had = part16_carry_in(a, tab, P, p_raw); // earlier chunks of the cohort (+) this one
+            if (TAB && tab.snt) part16_store(tab, P, p_raw, a, had);
             if (fin.slice_len) lane_acc_store_sliced(fin, p_raw, a); // multi-GPU shard, sliced exchange: straight into the exchange buffers
             if (fin.rate) {
                 const double limit = envelope_limit(C, cov);
@@ -2165,8 +2250,8 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
     const bool fast = !ctx->reduce_general && !co.rv.rd && !co.rv.rd_ext; // lines with their own RD column: the literal kernel
     // the shape error_reduce_u16_kernel takes (below).  From one tile per CU on it beats every cut of the general kernel along
     // lanes or samples (tools/sweep_tiles.py: 48 us against 62 at 768 tiles, 69 against 102 at 1280), so such a launch is not cut
-    const bool compact_shape = ctx->reduce_compact && fast && co.layout == AMPLI_RECORDS_U16 && !d_acc && (fin.rate || fin.slice_len) &&
-                               !fin.packed && !fin.accumulate && E == 0 && S <= RED_WAVES * FAST_MAX_CHUNK;
+    const bool compact_shape = ctx->reduce_compact && fast && co.layout == AMPLI_RECORDS_U16 && (!d_acc || fin.summary) && !fin.packed &&
+                               S <= RED_WAVES * FAST_MAX_CHUNK;
     const bool compact_uncut = compact_shape && (P + 63) / 64 >= ctx->n_cu;
     int G = ctx->reduce_groups;
     if (G != 1 && G != 2 && G != 4) {
@@ -2212,15 +2297,38 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
     if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
     ctx->last_reduce_kernel = compact_shape && G == 1 && splits == 1;
     if (ctx->last_reduce_kernel) {
-        hipLaunchKernelGGL(error_reduce_u16_kernel, dim3((unsigned)((P + 63) / 64)), dim3(256), 0, ctx->stream, co.rv, (long long)P, (int)S,
-                           (S + RED_WAVES - 1) / RED_WAVES, C, (int)cov, ctx->d_flags, fin);
+        AccPtrs tab = {};
+        if (d_acc) tab = to_ptrs(d_acc);
+        const dim3 cgrid((unsigned)((P + 63) / 64));
+        const int clen = (S + RED_WAVES - 1) / RED_WAVES;
+#define AMPLI_LAUNCH_U16(DUPV, TABV)                                                                                                             \
+    hipLaunchKernelGGL((error_reduce_u16_kernel<DUPV, TABV>), cgrid, dim3(256), 0, ctx->stream, co.rv, (long long)P, 0ll, (long long)P, d_dup_off, \
+                       (int)S, clen, C, (int)cov, ctx->d_flags, tab, fin)
+        if (E > 0) {
+            // the tiles with a position listed more than once go to the general kernel (at most one such tile per extra slot)
+            const long long ntiles = (P + 63) / 64;
+            int rcw = ensure_ws(ctx, (size_t)(ntiles + 1) * sizeof(unsigned));
+            if (rcw) return rcw;
+            unsigned *list = (unsigned *)ctx->ws;
+            HIP_TRY(ctx, hipMemsetAsync(list, 0, sizeof(unsigned), ctx->stream));
+            hipLaunchKernelGGL(dup_tiles_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx->stream, d_dup_off, (long long)P, list);
+            if (d_acc) AMPLI_LAUNCH_U16(true, true); else AMPLI_LAUNCH_U16(true, false);
+            int rcc = check_launch(ctx, "error_reduce_u16_kernel");
+            if (rcc) return rcc;
+            hipLaunchKernelGGL((error_reduce_kernel<true, 1, AMPLI_RECORDS_U16>), dim3((unsigned)std::min<long long>(E, ntiles)), dim3(256), 0, ctx->stream,
+                               co.rv, (long long)P, (long long)E, d_dup_off, (int)S, (int)first_sample, clen, C, (int)cov, d_acc ? (char *)d_acc->snt : (char *)nullptr,
+                               (size_t)0, off[0], off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, fin, (const unsigned *)list);
+            return check_launch(ctx, "error_reduce_kernel (tiles with positions listed more than once)");
+        }
+        if (d_acc) AMPLI_LAUNCH_U16(false, true); else AMPLI_LAUNCH_U16(false, false);
+#undef AMPLI_LAUNCH_U16
         return check_launch(ctx, "error_reduce_u16_kernel");
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE_L(FASTV, GV, UV)                                                                                      \
     hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P, \
                        (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],  \
-                       off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin)
+                       off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin, (const unsigned *)nullptr)
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                           \
     do {                                                         \
         if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_REDUCE_L(FASTV, GV, AMPLI_RECORDS_U24);      \
@@ -2305,7 +2413,29 @@ extern "C" int ampli_error_reduce_records(ampli_ctx *ctx, const ampli_records *r
     if ((d_rate != nullptr) != (d_code != nullptr)) return fail(ctx, AMPLI_E_INVALID, "error_reduce_records: rate and code come together");
     FinOut fo = {};
     fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
-    fo.accumulate = accumulate ? 1 : 0;
+    fo.accumulate = (accumulate & AMPLI_REDUCE_ACCUMULATE) ? 1 : 0;
+    fo.summary = (accumulate & AMPLI_REDUCE_SUMMARY) ? 1 : 0;
+    return error_reduce_impl(ctx, co, P, first_sample, C, cov, d_acc, fo);
+}
+
+// the LAST chunk of a shard's streamed cohort: table (+) chunk straight into the slice-major exchange buffers (no table -> slices pass;
+// a shard whose cohort is one chunk needs no table at all)
+extern "C" int ampli_error_reduce_records_sliced(ampli_ctx *ctx, const ampli_records *recs, int64_t P, int32_t first_sample, float C, int32_t cov,
+                                                 const ampli_acc_table *d_acc, int32_t accumulate, int32_t n_slices, double *d_sums, float *d_gm)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!d_sums || !d_gm || n_slices < 1) return fail(ctx, AMPLI_E_INVALID, "error_reduce_records_sliced: exchange buffers and n_slices >= 1 are required");
+    DevCohort co;
+    int rc = cohort_from_records(ctx, recs, P, co);
+    if (rc) return rc;
+    FinOut fo = {};
+    fo.accumulate = (accumulate & AMPLI_REDUCE_ACCUMULATE) ? 1 : 0;
+    fo.summary = (accumulate & AMPLI_REDUCE_SUMMARY) ? 1 : 0;
+    fo.slice_len = ampli_slice_len(P, n_slices);
+    fo.sl_group = ctx->grp_size;
+    fo.sl_fmt = ctx->slice_fmt; fo.sl_n = n_slices; fo.sl_flags = ctx->d_flags;
+    fo.sl_sums = d_sums + (size_t)ctx->grp_index * slice_planes(fo.sl_fmt) * (size_t)fo.slice_len;
+    fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
     return error_reduce_impl(ctx, co, P, first_sample, C, cov, d_acc, fo);
 }
 

@@ -51,6 +51,9 @@ struct HipApi {
     int (*poisson_call_records)(ampli_ctx *, const ampli_records *, int64_t, const float *, const uint8_t *, int32_t, int32_t, uint8_t *,
                                 ampli_call *, int64_t, unsigned long long *, double *, float *);
     int (*acc_to_slices)(ampli_ctx *, const ampli_acc_table *, int32_t, double *, float *);
+    int (*error_reduce_records_sliced)(ampli_ctx *, const ampli_records *, int64_t, int32_t, float, int32_t, const ampli_acc_table *, int32_t, int32_t,
+                                       double *, float *);
+    int (*last_reduce_kernel)(const ampli_ctx *);
     int (*event_create)(void **);
     int (*event_destroy)(void *);
     int (*event_record)(ampli_ctx *, void *);

@@ -594,10 +594,25 @@ int run_error_estimation(const EeArgs &a)
         uint8_t *d_code = dev.alloc<uint8_t>((size_t)P * 4), *d_gp = dev.alloc<uint8_t>((size_t)P * 4);
         int32_t *d_flags = dev.alloc<int32_t>(1);
         dev.check(dev.api->memset_d(dev.ctx, d_flags, 0, sizeof(int32_t)), "memset");
-        // the accumulator table every chunk of samples is folded into (EE:1057-1481 + the record loop of EE:1484-2544)
-        void *d_accbuf = dev.alloc<char>(dev.api->acc_bytes(P));
-        ampli_acc_table acc;
-        dev.check(dev.api->acc_bind(d_accbuf, P, &acc), "ampli_acc_bind");
+        // The accumulator table the chunks of a streamed cohort are folded into (EE:1057-1481 + the record loop of EE:1484-2544) is
+        // streaming state and nothing else here (AMPLI_REDUCE_SUMMARY), so the compact-state kernel may carry it from chunk to chunk;
+        // a cohort that arrives as ONE chunk needs no table at all: its launch finalises (one device) or stores slice-major (a shard).
+        ampli_acc_table acc{};
+        bool have_acc = false;
+        auto need_acc = [&] {
+            if (have_acc) return;
+            void *d_accbuf = dev.alloc<char>(dev.api->acc_bytes(P));
+            dev.check(dev.api->acc_bind(d_accbuf, P, &acc), "ampli_acc_bind");
+            have_acc = true;
+        };
+        // a shard's exchange buffers are wanted by its LAST chunk's launch, which writes them (slice-major sums + germ-max pairs)
+        void *xbufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        if (sh) {
+            hook(sh->ee_buffers(sh->user, P, xbufs), "ee_buffers");
+            for (void *b : xbufs)
+                if (!b) throw Error{AMPLI_E_INVALID, "shard hook ee_buffers returned a null buffer"};
+        }
+        int launches_compact = 0, launches_general = 0;
         void *ev = nullptr;
         dev.check(dev.api->event_create(&ev), "ampli_event_create");
         struct EvGuard { const HipApi *api; void *ev; ~EvGuard() { if (ev) api->event_destroy(ev); } } evg{dev.api, ev};
@@ -625,12 +640,20 @@ int run_error_estimation(const EeArgs &a)
                         for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl;
                     const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, false);
                     const bool fuse = c->last && !sh; // one device holds the whole panel: finalize in the last chunk's launch
+                    const bool only = c->last && chunks_done == 0; // the whole cohort (of this shard) in one chunk: no table
+                    if (!only) need_acc();
+                    const int32_t how = (chunks_done > 0 ? AMPLI_REDUCE_ACCUMULATE : 0) | AMPLI_REDUCE_SUMMARY;
                     {
                         PhaseClock::Scope sc(chunks_done == 0 && attempt == 0 ? "first_launch" : "launch"); // the first one loads the code object
-                        dev.check(dev.api->error_reduce_records(dev.ctx, &r, P, first_sample + c->first, C_value, cov, &acc, chunks_done > 0 ? 1 : 0,
-                                                                fuse ? d_rate : nullptr, fuse ? d_code : nullptr, nullptr, fuse ? d_germ : nullptr,
-                                                                fuse ? d_gp : nullptr, fuse ? d_flags : nullptr), "ampli_error_reduce_records");
+                        if (c->last && sh)
+                            dev.check(dev.api->error_reduce_records_sliced(dev.ctx, &r, P, first_sample + c->first, C_value, cov, only ? nullptr : &acc, how,
+                                                                           sh->count, (double *)xbufs[0], (float *)xbufs[1]), "ampli_error_reduce_records_sliced");
+                        else
+                            dev.check(dev.api->error_reduce_records(dev.ctx, &r, P, first_sample + c->first, C_value, cov, only ? nullptr : &acc, how,
+                                                                    fuse ? d_rate : nullptr, fuse ? d_code : nullptr, nullptr, fuse ? d_germ : nullptr,
+                                                                    fuse ? d_gp : nullptr, fuse ? d_flags : nullptr), "ampli_error_reduce_records");
                         dev.check(dev.api->event_record(dev.ctx, ev), "ampli_event_record");
+                        (dev.api->last_reduce_kernel(dev.ctx) == 1 ? launches_compact : launches_general) += 1;
                     }
                     const double w0 = now_s();
                     {
@@ -675,13 +698,8 @@ int run_error_estimation(const EeArgs &a)
             // -> plane-major table on every shard (include/amplisolve_hip.h, "Position-sliced merge")
             const int n = sh->count;
             const int64_t L = dev.api->slice_len(P, n);
-            void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-            hook(sh->ee_buffers(sh->user, P, bufs), "ee_buffers");
-            for (void *b : bufs)
-                if (!b) throw Error{AMPLI_E_INVALID, "shard hook ee_buffers returned a null buffer"};
-            if (chunks_done > 0) {
-                dev.check(dev.api->acc_to_slices(dev.ctx, &acc, n, (double *)bufs[0], (float *)bufs[1]), "ampli_acc_to_slices");
-            } else { // a shard without samples: zero sums, "no qualifying record" germ-max pairs
+            void **bufs = xbufs;
+            if (chunks_done == 0) { // a shard without samples: zero sums, "no qualifying record" germ-max pairs (else: written by the last chunk's launch)
                 std::vector<float> none((size_t)n * 8 * L);
                 for (int k = 0; k < n; ++k)
                     for (int j = 0; j < 8; ++j)
@@ -726,7 +744,10 @@ int run_error_estimation(const EeArgs &a)
         std::cout << "\nAmpliSolveErrorEstimation execution was successful. Results can be found at: " << out << std::endl;
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING panel " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done
-                      << " parse_busy " << parse_s << " device_wait " << wait_s << " record_MB " << rec_bytes_up / 1e6 << "\nTIMING finish " << t3 - t2 << "\nTIMING write " << t4 - t3 << std::endl;
+                      << " parse_busy " << parse_s << " device_wait " << wait_s << " record_MB " << rec_bytes_up / 1e6 << "\nTIMING finish " << t3 - t2 << "\nTIMING write " << t4 - t3
+                      // which error_reduce kernel each chunk's launch was (ampli_last_reduce_kernel): error_reduce_u16_kernel (compact state) / error_reduce_kernel
+                      << "\nTIMING reduce_launches " << launches_compact + launches_general << " error_reduce_u16_kernel " << launches_compact << " error_reduce_kernel " << launches_general
+                      << " accumulator_table " << (have_acc ? 1 : 0) << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;
     } catch (const Error &e) {

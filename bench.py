@@ -187,6 +187,10 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                                  "phases_s": {"panel": ee_t.get("panel"), "stream(parse+upload+reduce)": ee_t.get("stream"), "parser_busy": ee_t.get("stream.parse_busy"),
                                               "waiting_for_gpu": ee_t.get("stream.device_wait"), "table_write": ee_t.get("write")},
                                  "chunks": int(ee_t.get("stream.chunks", 0)),
+                                 # which error_reduce kernel each chunk's launch was (ampli_last_reduce_kernel, printed by the executable)
+                                 "reduce_launches": {"error_reduce_u16_kernel": int(ee_t.get("reduce_launches.error_reduce_u16_kernel", 0)),
+                                                     "error_reduce_kernel": int(ee_t.get("reduce_launches.error_reduce_kernel", 0)),
+                                                     "accumulator_table": bool(ee_t.get("reduce_launches.accumulator_table", 0))},
                                  # where the wall time goes: the phase clock of the executable (csrc/host/pipeline.cpp PhaseClock).
                                  # Entries without * lie on the main thread's path and add up to wall_in_main; entries with * ran
                                  # on other threads beside it (runtime start-up, parsers, by-product files, ring teardown)

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define AMPLI_ABI_VERSION 3
+#define AMPLI_ABI_VERSION 4
 #define AMPLI_ABSENT INT32_MIN
 /* record layouts, same field order in all of them:
  *   AMPLI_RECORDS_I32  int32 recs[n_samples][R][8], 32 B per record, absent: recs[..][0] == INT32_MIN
@@ -214,9 +214,25 @@ typedef struct ampli_records {
  * gives the table of the single pass.  With d_rate / d_code non-NULL the merged state is finalised in the same
  * launch (last chunk; outputs as ampli_error_finalize).  Fully asynchronous on the context's stream.
  */
+/* `accumulate` is a set of bits (0 / 1 as before):
+ *   AMPLI_REDUCE_ACCUMULATE  d_acc holds the state of the earlier samples (above)
+ *   AMPLI_REDUCE_SUMMARY     the caller takes d_acc as STREAMING STATE, not as the bookkeeping of record: gm_n may then count a
+ *                            chunk's qualifying records as none / one / two-or-more and gm_first may read -1 (unknown) -- what every
+ *                            merge, the sliced store and finalize ask of them is kept, every other plane is exact.  That is what lets
+ *                            the compact-state kernel (ampli_set_reduce_compact) carry a streamed uint16 cohort from chunk to chunk;
+ *                            chunks that take the general kernel (other layouts, lines with their own RD column) leave exact planes
+ *                            and the two compose in either order.  The command lines stream with this bit. */
+#define AMPLI_REDUCE_ACCUMULATE 1
+#define AMPLI_REDUCE_SUMMARY 2
 int ampli_error_reduce_records(ampli_ctx *ctx, const ampli_records *recs, int64_t P, int32_t first_sample, float C,
                                int32_t coverage_cutoff, const ampli_acc_table *d_acc, int32_t accumulate, float *d_rate,
                                uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present, int32_t *d_flags);
+/* The last chunk of a SHARD's streamed cohort (one process per GPU): d_acc (+) chunk goes straight into the slice-major
+ * exchange buffers of the position-sliced merge below (what ampli_error_reduce_sliced writes for a resident shard), and into
+ * d_acc as well when one is given.  d_acc may be NULL when the shard's cohort is this one chunk (accumulate == 0). */
+int ampli_error_reduce_records_sliced(ampli_ctx *ctx, const ampli_records *recs, int64_t P, int32_t first_sample, float C,
+                                      int32_t coverage_cutoff, const ampli_acc_table *d_acc, int32_t accumulate, int32_t n_slices,
+                                      double *d_sums, float *d_gm);
 
 /*
  * acc_merge -- ordered combine of nparts partial tables (parts[0] = earliest
@@ -460,10 +476,11 @@ int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_r
  * groups per wave of error_reduce (1, 2 or 4; 0 = automatic: 1 unless the panel is too small to fill the chip). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general, int32_t reduce_lane_groups);
 /* error_reduce for uint16 records with a compact per-position state (96 VGPRs: five waves per SIMD instead of four): taken by
- * ampli_error_estimate / ampli_error_reduce_records / ampli_error_reduce_sliced when on != 0 (the default) and the launch has the
- * shape it covers -- fast kernel, uint16 records, no position listed twice, one lane group, one sample split, no accumulator
- * table (finalize fused, or the shard's sums straight into the sliced exchange buffers), at most 4096 samples; every other
- * launch takes the general kernel.  Same results, bit for bit. */
+ * ampli_error_estimate / ampli_error_reduce_records(_sliced) / ampli_error_reduce_sliced when on != 0 (the default) and the launch
+ * has the shape it covers -- fast kernel, uint16 records, one lane group, one sample split, at most 4096 samples, and either no
+ * accumulator table (finalize fused, or the shard's sums straight into the sliced exchange buffers) or a table the caller takes
+ * as streaming state (AMPLI_REDUCE_SUMMARY).  Positions listed more than once (E > 0) are served: their tiles walk sample by
+ * sample, primary record then extras.  Every other launch takes the general kernel.  Same results, bit for bit. */
 int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
 /* Which kernel the context's latest error_reduce launch was: 0 = error_reduce_kernel (general), 1 = error_reduce_u16_kernel
  * (compact state); AMPLI_E_INVALID before the first launch.  For tests and the bench line, which name the kernel they measured. */

@@ -25,8 +25,14 @@ del normals, tumours
 cap = 1 << 20
 
 
+JOIN = os.environ.get("SP_JOIN", "0") == "1"   # both ranges joined at the end of EVERY pass (a library call that forks and joins inside)
+PRIO = os.environ.get("SP_PRIO", "0") == "1"   # the first range's stream at high priority (its kernels dispatch first)
+_made = [0]
+
+
 def make_lane(p0, p1):
-    st = torch.cuda.Stream(device=0)
+    st = torch.cuda.Stream(device=0, priority=-1 if (PRIO and _made[0] % 2 == 0 and p0 == 0) else 0)
+    _made[0] += 1
     with torch.cuda.stream(st):
         c = Context(0)
         c.set_record_layout("u16")
@@ -56,11 +62,17 @@ def timed(lanes, steps=50, warm=5):
     e0.record(torch.cuda.current_stream())
     for l in lanes:  # every lane starts behind the common start event
         l["st"].wait_event(e0)
+    cur = torch.cuda.current_stream()
     for _ in range(steps):
         for l in lanes:
             step(l)
+        if JOIN and len(lanes) > 1:  # join, then fork again: the next pass starts when every range of this one is done
+            for l in lanes:
+                cur.wait_stream(l["st"])
+            for l in lanes:
+                l["st"].wait_stream(cur)
     for l in lanes:
-        torch.cuda.current_stream().wait_stream(l["st"])
+        cur.wait_stream(l["st"])
     e1.record(torch.cuda.current_stream())
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
@@ -68,7 +80,8 @@ def timed(lanes, steps=50, warm=5):
 
 whole = make_lane(0, P)
 torch.cuda.synchronize()
-for rep in range(3):
+print(f"join at the end of every pass: {JOIN}; first range at high priority: {PRIO}", flush=True)
+for rep in range(int(os.environ.get("SP_REPS", "3"))):
     print(f"unsplit, one stream: {timed([whole]) * 1e3:7.1f} us per pass", flush=True)
     for first in [int(a) for a in sys.argv[1:]] or [1280, 1024, 782]:
         a, b = make_lane(0, first * 64), make_lane(first * 64, P)
