@@ -109,6 +109,9 @@ HIP_SYMBOLS = {
     "ampli_roundtrip_batch": (C.c_int, [vp, vp, i64, vp]),
     "ampli_synth_fill": (C.c_int, [vp, vp, i64, i32, i32, u64, i32, i32]),
     "ampli_synth_ref": (C.c_int, [vp, vp, i64, u64]),
+    "ampli_set_ranges": (C.c_int, [vp, i32]),
+    "ampli_ranges_join": (C.c_int, [vp]),
+    "ampli_range_event_record": (C.c_int, [vp, i32, vp]),
     "ampli_set_reduce_compact": (C.c_int, [vp, i32]),
     "ampli_last_reduce_kernel": (C.c_int, [vp]),
     "ampli_set_tuning": (C.c_int, [vp, i32, i32, i32]),

@@ -198,6 +198,18 @@ class Context:
     def wait_calls(self):
         self._check(self.lib.ampli_wait_calls(self.h))
 
+    def set_ranges(self, n: int):
+        """error_estimate / poisson_call (prefilter) over n tile-aligned position ranges on n streams (include/amplisolve_hip.h,
+        ampli_set_ranges); 1 = off.  The section closes at the next other call on this context."""
+        self._check(self.lib.ampli_set_ranges(self.h, n))
+
+    def ranges_join(self):
+        self._check(self.lib.ampli_ranges_join(self.h))
+
+    def range_record(self, rng: int, ev):
+        """record `ev` on range `rng`'s stream without closing the section (ampli_range_event_record)"""
+        self._check(self.lib.ampli_range_event_record(self.h, rng, ev))
+
     def set_reduce_compact(self, on: bool):
         """error_estimate on uint16 records through the compact-state kernel (five waves per SIMD) where its shape applies; same results"""
         self._check(self.lib.ampli_set_reduce_compact(self.h, int(bool(on))))

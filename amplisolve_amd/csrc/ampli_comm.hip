@@ -209,7 +209,7 @@ extern "C" int ampli_comm_create(ampli_ctx *ctx, int32_t rank, int32_t world, co
 extern "C" void ampli_comm_destroy(ampli_comm *c)
 {
     if (!c) return;
-    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hipStreamSynchronize(main_stream(c->ctx));
     if (c->d_small) (void)hipFree(c->d_small);
     if (c->comm) g_rccl.CommDestroy(c->comm);
     delete c;
@@ -219,7 +219,7 @@ extern "C" void ampli_comm_destroy(ampli_comm *c)
 extern "C" int ampli_comm_reduce_scatter_f64(ampli_comm *c, const double *d_send, double *d_recv, int64_t count)
 {
     if (!c || !d_send || !d_recv || count <= 0) return AMPLI_E_INVALID;
-    RCCL_TRY(c, g_rccl.ReduceScatter(d_send, d_recv, (size_t)count, ncclFloat64, ncclSum, c->comm, c->ctx->stream));
+    RCCL_TRY(c, g_rccl.ReduceScatter(d_send, d_recv, (size_t)count, ncclFloat64, ncclSum, c->comm, main_stream(c->ctx)));
     return AMPLI_OK;
 }
 
@@ -229,8 +229,8 @@ extern "C" int ampli_comm_all_to_all_f32(ampli_comm *c, const float *d_send, flo
     if (!c || !d_send || !d_recv || count <= 0) return AMPLI_E_INVALID;
     RCCL_TRY(c, g_rccl.GroupStart());
     for (int k = 0; k < c->world; ++k) {
-        RCCL_TRY(c, g_rccl.Send(d_send + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, c->ctx->stream));
-        RCCL_TRY(c, g_rccl.Recv(d_recv + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, c->ctx->stream));
+        RCCL_TRY(c, g_rccl.Send(d_send + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, main_stream(c->ctx)));
+        RCCL_TRY(c, g_rccl.Recv(d_recv + (size_t)k * count, (size_t)count, ncclFloat32, k, c->comm, main_stream(c->ctx)));
     }
     RCCL_TRY(c, g_rccl.GroupEnd());
     return AMPLI_OK;
@@ -239,7 +239,7 @@ extern "C" int ampli_comm_all_to_all_f32(ampli_comm *c, const float *d_send, flo
 extern "C" int ampli_comm_all_gather_bytes(ampli_comm *c, const void *d_send, void *d_recv, int64_t bytes)
 {
     if (!c || !d_send || !d_recv || bytes <= 0) return AMPLI_E_INVALID;
-    RCCL_TRY(c, g_rccl.AllGather(d_send, d_recv, (size_t)bytes, ncclUint8, c->comm, c->ctx->stream));
+    RCCL_TRY(c, g_rccl.AllGather(d_send, d_recv, (size_t)bytes, ncclUint8, c->comm, main_stream(c->ctx)));
     return AMPLI_OK;
 }
 
@@ -247,10 +247,10 @@ extern "C" int ampli_comm_all_gather_bytes(ampli_comm *c, const void *d_send, vo
 extern "C" int ampli_comm_all_reduce_max_i32(ampli_comm *c, int32_t *values, int32_t n)
 {
     if (!c || !values || n < 1 || n > 64) return AMPLI_E_INVALID;
-    HIP_TRY(c->ctx, hipMemcpyAsync(c->d_small, values, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->ctx->stream));
-    RCCL_TRY(c, g_rccl.AllReduce(c->d_small, c->d_small, (size_t)n, ncclInt32, ncclMax, c->comm, c->ctx->stream));
-    HIP_TRY(c->ctx, hipMemcpyAsync(values, c->d_small, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->ctx->stream));
-    HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+    HIP_TRY(c->ctx, hipMemcpyAsync(c->d_small, values, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, main_stream(c->ctx)));
+    RCCL_TRY(c, g_rccl.AllReduce(c->d_small, c->d_small, (size_t)n, ncclInt32, ncclMax, c->comm, main_stream(c->ctx)));
+    HIP_TRY(c->ctx, hipMemcpyAsync(values, c->d_small, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, main_stream(c->ctx)));
+    HIP_TRY(c->ctx, hipStreamSynchronize(main_stream(c->ctx)));
     return AMPLI_OK;
 }
 
@@ -259,11 +259,11 @@ extern "C" int ampli_comm_exclusive_sum_i64(ampli_comm *c, int64_t mine, int64_t
 {
     if (!c || !before || c->world > 63) return AMPLI_E_INVALID;
     long long *d = (long long *)c->d_small; // word 0: mine; words 1..world: gathered
-    HIP_TRY(c->ctx, hipMemcpyAsync(d, &mine, sizeof(long long), hipMemcpyHostToDevice, c->ctx->stream));
-    RCCL_TRY(c, g_rccl.AllGather(d, d + 1, 1, ncclInt64, c->comm, c->ctx->stream));
+    HIP_TRY(c->ctx, hipMemcpyAsync(d, &mine, sizeof(long long), hipMemcpyHostToDevice, main_stream(c->ctx)));
+    RCCL_TRY(c, g_rccl.AllGather(d, d + 1, 1, ncclInt64, c->comm, main_stream(c->ctx)));
     long long all[64];
-    HIP_TRY(c->ctx, hipMemcpyAsync(all, d + 1, (size_t)c->world * sizeof(long long), hipMemcpyDeviceToHost, c->ctx->stream));
-    HIP_TRY(c->ctx, hipStreamSynchronize(c->ctx->stream));
+    HIP_TRY(c->ctx, hipMemcpyAsync(all, d + 1, (size_t)c->world * sizeof(long long), hipMemcpyDeviceToHost, main_stream(c->ctx)));
+    HIP_TRY(c->ctx, hipStreamSynchronize(main_stream(c->ctx)));
     long long s_ = 0;
     for (int k = 0; k < c->rank; ++k) s_ += all[k];
     *before = s_;

@@ -10,6 +10,21 @@
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+constexpr int AMPLI_MAX_RANGES = 4;
+// poisson_call's prefilter queue (PcItem) + its shard counters (two counter arrays, used alternately)
+struct AmpliQueue {
+    void *items = nullptr;
+    size_t n_items = 0;
+    unsigned long long *n = nullptr;
+    unsigned parity = 0;
+};
+// one position range of a context with ranges: its stream, its queue, the event the context's stream waits for when the section closes
+struct AmpliLane {
+    hipStream_t stream = nullptr; // lane 0: unused (the context's stream)
+    hipEvent_t done = nullptr;
+    AmpliQueue q;
+};
+
 struct ampli_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -26,11 +41,14 @@ struct ampli_ctx {
     int slice_fmt = 0;               // AMPLI_SLICE_WIDE / AMPLI_SLICE_SLIM: what the sums of the sliced exchange look like (ampli_set_slice_format)
     int rec_layout = 0;     // record layout of every d_recs / d_trecs argument: AMPLI_RECORDS_I32 / _U16 / _U24
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
-    void *queue = nullptr;  // poisson_call prefilter queue (PcItem) + its shard counters
-    size_t queue_items = 0;
     size_t queue_min_items = 0; // ampli_set_queue_items
-    unsigned long long *queue_n = nullptr; // two counter arrays, used alternately
-    unsigned queue_parity = 0;
+    // Position ranges on concurrent streams (ampli_set_ranges): lane 0 is the context's own stream, lanes 1.. own theirs.  Every lane
+    // has its poisson_call prefilter queue (lane 0's is the only one a context without ranges ever uses).
+    int n_ranges = 1;
+    AmpliLane lanes[AMPLI_MAX_RANGES];
+    hipEvent_t ev_fork = nullptr;
+    bool ranges_open = false; // lanes 1.. hold work the context's stream has not waited for yet
+    long long ranges_P = 0;   // the panel the open section is cut for
     // optional: the drain kernel of poisson_call on a side stream (ampli_set_async_drain)
     int async_drain = 0;
     hipStream_t side = nullptr;
@@ -69,3 +87,13 @@ static inline int check_launch(ampli_ctx *ctx, const char *what)
     return AMPLI_OK;
 }
 
+
+// Every ordinary entry point enqueues on main_stream(ctx): if position ranges are still running on their own streams
+// (ampli_set_ranges), the context's stream first waits for them -- so whatever follows sees their outputs and may overwrite their
+// inputs.  Only the range-aware launches of ampli_error_estimate / ampli_poisson_call use ctx->stream (lane 0) as it is.
+int ampli_ranges_join_internal(ampli_ctx *ctx);
+static inline hipStream_t main_stream(ampli_ctx *ctx)
+{
+    if (ctx->ranges_open) (void)ampli_ranges_join_internal(ctx);
+    return ctx->stream;
+}

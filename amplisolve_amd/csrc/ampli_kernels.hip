@@ -100,8 +100,14 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
-    if (ctx->queue) (void)hipFree(ctx->queue);
-    if (ctx->queue_n) (void)hipFree(ctx->queue_n);
+    for (int k = 0; k < AMPLI_MAX_RANGES; ++k) {
+        AmpliLane &l = ctx->lanes[k];
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.q.items) (void)hipFree(l.q.items);
+        if (l.q.n) (void)hipFree(l.q.n);
+        if (l.done) (void)hipEventDestroy(l.done);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->d_lgtab) (void)hipFree(ctx->d_lgtab);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->ev_stream_done) (void)hipEventDestroy(ctx->ev_stream_done);
@@ -111,7 +117,7 @@ extern "C" void ampli_ctx_destroy(ampli_ctx *ctx)
 }
 
 extern "C" const char *ampli_last_error(ampli_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
-extern "C" void *ampli_stream(ampli_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" void *ampli_stream(ampli_ctx *ctx) { return ctx ? (void *)main_stream(ctx) : nullptr; }
 
 // main stream waits for the drain kernel still running on the side stream (no host block)
 static int join_drain(ampli_ctx *ctx)
@@ -144,6 +150,86 @@ extern "C" int ampli_wait_calls(ampli_ctx *ctx)
 }
 
 // ---------------------------------------------------------------------------
+// Position ranges on concurrent streams (ampli_set_ranges; include/amplisolve_hip.h).  With n > 1 ranges ampli_error_estimate and
+// ampli_poisson_call (prefilter mode) cut the panel into n tile-aligned ranges of positions; range 0 runs on the context's stream,
+// range k on a stream of its own, each range's poisson_call behind its own error_estimate.  The section opens with a fork (the
+// lanes' streams wait for everything enqueued on the context's stream so far) and stays open across calls: back-to-back passes
+// over independent batches overlap -- one range's poisson_call and another's error_reduce fill each other's partly filled rounds
+// of workgroups.  It closes (the context's stream waits for every lane) at the next ordinary call: main_stream().
+// ---------------------------------------------------------------------------
+static void range_cuts(const long long P, const int n, long long cut[AMPLI_MAX_RANGES + 1])
+{
+    const long long tiles = (P + 63) / 64;
+    for (int k = 0; k < n; ++k) cut[k] = std::min<long long>(P, (tiles * k / n) * 64);
+    cut[n] = P;
+}
+
+static inline hipStream_t lane_stream(ampli_ctx *ctx, const int k) { return k == 0 ? ctx->stream : ctx->lanes[k].stream; }
+
+int ampli_ranges_join_internal(ampli_ctx *ctx)
+{
+    if (!ctx->ranges_open) return AMPLI_OK;
+    ctx->ranges_open = false;
+    for (int k = 1; k < ctx->n_ranges; ++k) {
+        HIP_TRY(ctx, hipEventRecord(ctx->lanes[k].done, ctx->lanes[k].stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[k].done, 0));
+    }
+    return AMPLI_OK;
+}
+
+// open the section for a panel of P positions (or keep it open if it is cut for the same panel)
+static int ranges_fork(ampli_ctx *ctx, const long long P)
+{
+    if (ctx->ranges_open && ctx->ranges_P == P) return AMPLI_OK;
+    { int rc = ampli_ranges_join_internal(ctx); if (rc) return rc; }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    for (int k = 1; k < ctx->n_ranges; ++k) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[k].stream, ctx->ev_fork, 0));
+    ctx->ranges_open = true;
+    ctx->ranges_P = P;
+    return AMPLI_OK;
+}
+
+// ranges apply to a launch over P positions: switched on, not capturing, and every range at least two tiles
+static bool ranges_apply(ampli_ctx *ctx, const long long P)
+{
+    if (ctx->n_ranges <= 1 || (P + 63) / 64 < 2ll * ctx->n_ranges) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (ctx->stream && hipStreamIsCapturing(ctx->stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive) return false;
+    return true;
+}
+
+extern "C" int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (n_ranges < 1 || n_ranges > AMPLI_MAX_RANGES) return fail(ctx, AMPLI_E_INVALID, "set_ranges: 1 .. 4 ranges");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    { int rc = ampli_ranges_join_internal(ctx); if (rc) return rc; }
+    if (n_ranges > 1 && !ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    for (int k = 1; k < n_ranges; ++k) {
+        AmpliLane &l = ctx->lanes[k];
+        if (!l.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        if (!l.done) HIP_TRY(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+    }
+    ctx->n_ranges = n_ranges;
+    return AMPLI_OK;
+}
+
+extern "C" int ampli_ranges_join(ampli_ctx *ctx)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    return ampli_ranges_join_internal(ctx);
+}
+
+// an event on range `range`'s stream, WITHOUT closing the section: brackets that range's share of the calls around it (the
+// kernels' durations under the overlap the ranges exist for)
+extern "C" int ampli_range_event_record(ampli_ctx *ctx, int32_t range, void *ev)
+{
+    if (!ctx || !ev || range < 0 || range >= ctx->n_ranges) return AMPLI_E_INVALID;
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, lane_stream(ctx, range)));
+    return AMPLI_OK;
+}
+
+// ---------------------------------------------------------------------------
 // hipGraph capture of a sequence of ampli_* calls (launch-bound small panels: a pass over a 10k-position panel is
 // four ~10 us kernels, so the launches themselves dominate).  Capture needs a real stream (AMPLI_STREAM_OWN or any
 // non-null stream) and warm workspaces: run the sequence once before capturing; a call that would have to allocate
@@ -160,9 +246,9 @@ static bool is_capturing(ampli_ctx *ctx)
 extern "C" int ampli_graph_begin(ampli_ctx *ctx)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    if (!ctx->stream) return fail(ctx, AMPLI_E_INVALID, "graph capture needs a non-default stream (AMPLI_STREAM_OWN)");
+    if (!main_stream(ctx)) return fail(ctx, AMPLI_E_INVALID, "graph capture needs a non-default stream (AMPLI_STREAM_OWN)");
     { int rc = join_drain(ctx); if (rc) return rc; }
-    HIP_TRY(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    HIP_TRY(ctx, hipStreamBeginCapture(main_stream(ctx), hipStreamCaptureModeThreadLocal));
     return AMPLI_OK;
 }
 
@@ -170,7 +256,7 @@ extern "C" int ampli_graph_end(ampli_ctx *ctx, void **graph_exec)
 {
     if (!ctx || !graph_exec) return AMPLI_E_INVALID;
     hipGraph_t g = nullptr;
-    HIP_TRY(ctx, hipStreamEndCapture(ctx->stream, &g));
+    HIP_TRY(ctx, hipStreamEndCapture(main_stream(ctx), &g));
     hipGraphExec_t e = nullptr;
     hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -182,7 +268,7 @@ extern "C" int ampli_graph_end(ampli_ctx *ctx, void **graph_exec)
 extern "C" int ampli_graph_launch(ampli_ctx *ctx, void *graph_exec)
 {
     if (!ctx || !graph_exec) return AMPLI_E_INVALID;
-    HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, ctx->stream));
+    HIP_TRY(ctx, hipGraphLaunch((hipGraphExec_t)graph_exec, main_stream(ctx)));
     return AMPLI_OK;
 }
 
@@ -195,7 +281,7 @@ extern "C" int ampli_sync(ampli_ctx *ctx)
 {
     if (!ctx) return AMPLI_E_INVALID;
     { int rc = join_drain(ctx); if (rc) return rc; }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(main_stream(ctx)));
     return AMPLI_OK;
 }
 
@@ -230,20 +316,20 @@ extern "C" int ampli_dev_free(ampli_ctx *ctx, void *d_p)
 extern "C" int ampli_copy_h2d(ampli_ctx *ctx, void *d_dst, const void *src, size_t bytes)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, main_stream(ctx)));
     return AMPLI_OK;
 }
 extern "C" int ampli_copy_d2h(ampli_ctx *ctx, void *dst, const void *d_src, size_t bytes)
 {
     if (!ctx) return AMPLI_E_INVALID;
     { int rc = join_drain(ctx); if (rc) return rc; }
-    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, main_stream(ctx)));
     return AMPLI_OK;
 }
 extern "C" int ampli_memset_d(ampli_ctx *ctx, void *d_dst, int byte, size_t bytes)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    HIP_TRY(ctx, hipMemsetAsync(d_dst, byte, bytes, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(d_dst, byte, bytes, main_stream(ctx)));
     return AMPLI_OK;
 }
 
@@ -259,7 +345,7 @@ extern "C" int ampli_event_destroy(void *ev) { return hipEventDestroy((hipEvent_
 extern "C" int ampli_event_record(ampli_ctx *ctx, void *ev)
 {
     if (!ctx) return AMPLI_E_INVALID;
-    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, main_stream(ctx)));
     return AMPLI_OK;
 }
 extern "C" int ampli_event_sync(void *ev) { return hipEventSynchronize((hipEvent_t)ev) == hipSuccess ? AMPLI_OK : AMPLI_E_HIP; }
@@ -328,9 +414,9 @@ extern "C" int ampli_ctx_flags(ampli_ctx *ctx, int32_t *out, int32_t clear)
 {
     if (!ctx || !out) return AMPLI_E_INVALID;
     { int rc = join_drain(ctx); if (rc) return rc; }
-    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (clear) HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_flags, sizeof(int), hipMemcpyDeviceToHost, main_stream(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(main_stream(ctx)));
+    if (clear) HIP_TRY(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof(int), main_stream(ctx)));
     return AMPLI_OK;
 }
 
@@ -1842,8 +1928,11 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
     const int T, const int rows_per_wave, const unsigned gy, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
     const unsigned char *__restrict__ ref_code,
     const int cov, PcItem *__restrict__ queue, const long long queue_per_shard, unsigned long long *__restrict__ queue_n,
-    unsigned char *__restrict__ call_mask, int *__restrict__ flags, unsigned long long *__restrict__ n_calls)
+    unsigned char *__restrict__ call_mask, int *__restrict__ flags, unsigned long long *__restrict__ n_calls,
+    const long long r_lo, const long long r_hi, const unsigned shard_lo, const unsigned shard_n)
 {
+    // records [r_lo, r_hi) of every sample's R = P + E (the whole row, or one range of a context with position ranges: r_lo a
+    // multiple of 64, the call list's shards [shard_lo, shard_lo + shard_n) are this launch's)
     constexpr int RB = rec_bytes_of<LAY>();
     __shared__ PcItem stage[4][PC_STAGE];
     int staged = 0; // wave-uniform
@@ -1852,16 +1941,16 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
     const long long R = P + E;
     // the call-list counters are reset here: only the drain kernel, which starts after this one has finished,
     // appends to the list
-    if (n_calls && blockIdx.x == 0 && threadIdx.x < AMPLI_CALL_SHARDS) n_calls[threadIdx.x * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
+    if (n_calls && blockIdx.x == 0 && threadIdx.x < shard_n) n_calls[(shard_lo + threadIdx.x) * AMPLI_CALL_COUNTER_STRIDE] = 0ull;
     unsigned tile, y;
     pc_block_map(blockIdx.x, gy, tile, y);
-    const long long r_raw = (long long)tile * 64 + lane;
+    const long long r_raw = r_lo + (long long)tile * 64 + lane;
     const int t0 = ((int)y * 4 + wave) * rows_per_wave; // this wave's run of rows
     const int nt_rows = min(rows_per_wave, T - t0);
     // padding workgroups of the XCD mapping and waves beyond the last row only clear their share of the mask (below)
-    const bool has_rows = (long long)tile * 64 < R && nt_rows > 0;
-    const bool valid = r_raw < R;
-    const long long r = valid ? r_raw : R - 1;
+    const bool has_rows = r_lo + (long long)tile * 64 < r_hi && nt_rows > 0;
+    const bool valid = r_raw < r_hi;
+    const long long r = valid ? r_raw : r_hi - 1;
     // Everything the row loop needs from memory is REQUESTED first -- the position's reference code, its eight thresholds, the
     // first record -- and only then is the wave's share of the call mask cleared: written the other way round, the loads queue
     // behind the mask stores (vmcnt counts both, in order) and behind one another (two dependent round trips before row 0).
@@ -1898,12 +1987,27 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
     // of the mask's bytes -- whole 128-byte lines, one store instruction per 256 bytes -- rather than the 64 scattered
     // bytes per row that belong to its own records (partial-line writes cost the streaming kernel ~10 % in the loop).
     // (Clearing when a wave leaves instead of when it starts was measured twice: no faster.)
-    {
+    if (r_lo == 0 && r_hi == R) {
         const size_t m4 = ((size_t)T * (size_t)R + 3) / 4;       // the mask as dwords (the buffer is padded to a multiple of 4)
         const size_t share = (size_t)rows_per_wave * 16;         // dwords per wave: grid waves x share >= m4
         const size_t w0 = ((size_t)blockIdx.x * 4 + wave) * share;
         const size_t w1 = w0 + share < m4 ? w0 + share : m4;
         for (size_t o = w0 + lane; o < w1; o += 64) ((unsigned *)call_mask)[o] = 0u;
+    } else {
+        // a range owns bytes [t R + r_lo, t R + r_hi) of every row t: T segments of seg dwords (the host only cuts ranges when R,
+        // r_lo and r_hi are multiples of 4), cleared in the same contiguous shares, a share wrapping from one row's segment to the next's
+        const size_t seg = (size_t)(r_hi - r_lo) >> 2, m4 = (size_t)T * seg;
+        const size_t share = (size_t)rows_per_wave * 16;
+        const size_t w0 = ((size_t)blockIdx.x * 4 + wave) * share;
+        const size_t w1 = w0 + share < m4 ? w0 + share : m4;
+        if (w0 < w1) {
+            const size_t row0 = w0 / seg, off0 = w0 - row0 * seg; // wave-uniform
+            for (size_t i = lane; w0 + i < w1; i += 64) {
+                size_t o = off0 + i, row = row0;
+                while (o >= seg) { o -= seg; ++row; }
+                ((unsigned *)call_mask)[((row * (size_t)R + (size_t)r_lo) >> 2) + o] = 0u;
+            }
+        }
     }
     if (!has_rows) return;
     float te[2][4]; // effective error per strand / nucleotide
@@ -1975,7 +2079,7 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
 __global__ __launch_bounds__(256) void poisson_drain_kernel(
     const PcItem *__restrict__ queue, const long long queue_per_shard, const unsigned long long *__restrict__ queue_n,
     const long long R, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls, const long long capacity,
-    unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n)
+    unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n, const unsigned shard_lo, const unsigned shard_n)
 {
     constexpr int IPB = 128; // items per workgroup pass
     // the counter array of the NEXT poisson_call (the other half of a double buffer; its last reader, the previous
@@ -2024,7 +2128,7 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
             const unsigned long long bal = __ballot(emit);
             if (bal) {
                 const int lane = threadIdx.x & 63, leader = (int)__ffsll((long long)bal) - 1;
-                const unsigned cs = (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) % AMPLI_CALL_SHARDS);
+                const unsigned cs = shard_lo + (unsigned)((blockIdx.y * gridDim.x + blockIdx.x) % shard_n); // this launch's shards of the call list
                 const long long per = capacity / AMPLI_CALL_SHARDS;
                 unsigned long long base = 0;
                 if (lane == leader) base = atomicAdd(&n_calls[cs * AMPLI_CALL_COUNTER_STRIDE], (unsigned long long)__popcll(bal));
@@ -2140,7 +2244,7 @@ static int ensure_ws(ampli_ctx *ctx, size_t bytes)
 {
     if (ctx->ws_bytes >= bytes) return AMPLI_OK;
     if (is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "workspace would have to grow while capturing: run the sequence once first");
-    if (ctx->ws) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
+    if (ctx->ws) { HIP_TRY(ctx, hipStreamSynchronize(main_stream(ctx))); (void)hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_bytes = 0; }
     if (hipMalloc(&ctx->ws, bytes) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "workspace hipMalloc failed");
     ctx->ws_bytes = bytes;
     return AMPLI_OK;
@@ -2168,7 +2272,7 @@ static AccPtrs to_ptrs(const ampli_acc_table *t)
 
 static int launch_finalize(ampli_ctx *ctx, const AccPtrs &t, long long P, float C, int cov, const FinOut &fo)
 {
-    hipLaunchKernelGGL(error_finalize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, t, P, C, cov, fo);
+    hipLaunchKernelGGL(error_finalize_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), t, P, C, cov, fo);
     return check_launch(ctx, "error_finalize_kernel");
 }
 
@@ -2299,34 +2403,46 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
     if (ctx->last_reduce_kernel) {
         AccPtrs tab = {};
         if (d_acc) tab = to_ptrs(d_acc);
-        const dim3 cgrid((unsigned)((P + 63) / 64));
         const int clen = (S + RED_WAVES - 1) / RED_WAVES;
-#define AMPLI_LAUNCH_U16(DUPV, TABV)                                                                                                             \
-    hipLaunchKernelGGL((error_reduce_u16_kernel<DUPV, TABV>), cgrid, dim3(256), 0, ctx->stream, co.rv, (long long)P, 0ll, (long long)P, d_dup_off, \
-                       (int)S, clen, C, (int)cov, ctx->d_flags, tab, fin)
+#define AMPLI_LAUNCH_U16(DUPV, TABV, ST, LO, HI)                                                                                                   \
+    hipLaunchKernelGGL((error_reduce_u16_kernel<DUPV, TABV>), dim3((unsigned)(((HI) - (LO) + 63) / 64)), dim3(256), 0, ST, co.rv, (long long)P,      \
+                       (long long)(LO), (long long)(HI), d_dup_off, (int)S, clen, C, (int)cov, ctx->d_flags, tab, fin)
         if (E > 0) {
             // the tiles with a position listed more than once go to the general kernel (at most one such tile per extra slot)
+            hipStream_t st = main_stream(ctx);
             const long long ntiles = (P + 63) / 64;
             int rcw = ensure_ws(ctx, (size_t)(ntiles + 1) * sizeof(unsigned));
             if (rcw) return rcw;
             unsigned *list = (unsigned *)ctx->ws;
-            HIP_TRY(ctx, hipMemsetAsync(list, 0, sizeof(unsigned), ctx->stream));
-            hipLaunchKernelGGL(dup_tiles_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, ctx->stream, d_dup_off, (long long)P, list);
-            if (d_acc) AMPLI_LAUNCH_U16(true, true); else AMPLI_LAUNCH_U16(true, false);
+            HIP_TRY(ctx, hipMemsetAsync(list, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(dup_tiles_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, st, d_dup_off, (long long)P, list);
+            if (d_acc) AMPLI_LAUNCH_U16(true, true, st, 0, P); else AMPLI_LAUNCH_U16(true, false, st, 0, P);
             int rcc = check_launch(ctx, "error_reduce_u16_kernel");
             if (rcc) return rcc;
-            hipLaunchKernelGGL((error_reduce_kernel<true, 1, AMPLI_RECORDS_U16>), dim3((unsigned)std::min<long long>(E, ntiles)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL((error_reduce_kernel<true, 1, AMPLI_RECORDS_U16>), dim3((unsigned)std::min<long long>(E, ntiles)), dim3(256), 0, st,
                                co.rv, (long long)P, (long long)E, d_dup_off, (int)S, (int)first_sample, clen, C, (int)cov, d_acc ? (char *)d_acc->snt : (char *)nullptr,
                                (size_t)0, off[0], off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, fin, (const unsigned *)list);
             return check_launch(ctx, "error_reduce_kernel (tiles with positions listed more than once)");
         }
-        if (d_acc) AMPLI_LAUNCH_U16(false, true); else AMPLI_LAUNCH_U16(false, false);
+        if (ranges_apply(ctx, P)) { // position ranges on concurrent streams (ampli_set_ranges)
+            int rcf = ranges_fork(ctx, P);
+            if (rcf) return rcf;
+            long long cut[AMPLI_MAX_RANGES + 1];
+            range_cuts(P, ctx->n_ranges, cut);
+            for (int k = 0; k < ctx->n_ranges; ++k) {
+                hipStream_t st = lane_stream(ctx, k);
+                if (d_acc) AMPLI_LAUNCH_U16(false, true, st, cut[k], cut[k + 1]); else AMPLI_LAUNCH_U16(false, false, st, cut[k], cut[k + 1]);
+            }
+            return check_launch(ctx, "error_reduce_u16_kernel");
+        }
+        hipStream_t st = main_stream(ctx);
+        if (d_acc) AMPLI_LAUNCH_U16(false, true, st, 0, P); else AMPLI_LAUNCH_U16(false, false, st, 0, P);
 #undef AMPLI_LAUNCH_U16
         return check_launch(ctx, "error_reduce_u16_kernel");
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
 #define AMPLI_LAUNCH_REDUCE_L(FASTV, GV, UV)                                                                                      \
-    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P, \
+    hipLaunchKernelGGL((error_reduce_kernel<FASTV, GV, UV>), grid, dim3(256), 0, main_stream(ctx), co.rv, (long long)P, \
                        (long long)E, d_dup_off, (int)S, (int)first_sample, chunk_len, C, (int)cov, out_base, stride, off[0],  \
                        off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, kfin, (const unsigned *)nullptr)
 #define AMPLI_LAUNCH_REDUCE(FASTV, GV)                           \
@@ -2350,13 +2466,13 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
     if (rc) return rc;
     if (splits > 1) {
         char *merged = d_acc ? (char *)d_acc->snt : (char *)ctx->ws + off[8] * (size_t)splits;
-        hipLaunchKernelGGL(acc_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, merged,
+        hipLaunchKernelGGL(acc_merge_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), merged,
                            (const char *)ctx->ws, stride, splits, (long long)P, off[0], off[1], off[2], off[3], off[4], off[5],
                            off[6], off[7], fin.accumulate ? (const char *)d_acc->snt : (const char *)nullptr);
         rc = check_launch(ctx, "acc_merge_kernel");
         if (rc) return rc;
         if (fin.packed) {
-            hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc),
+            hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, main_stream(ctx), to_ptrs(d_acc),
                                (long long)P, fin.packed);
             rc = check_launch(ctx, "acc_pack_kernel");
             if (rc) return rc;
@@ -2366,7 +2482,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
             t.snt = (double *)(merged + off[0]); t.srd = (long long *)(merged + off[1]); t.cnt = (int *)(merged + off[2]);
             t.nrec = (int *)(merged + off[3]); t.gm_n = (int *)(merged + off[4]); t.gm_first = (int *)(merged + off[5]);
             t.gm_first_af = (float *)(merged + off[6]); t.gm_rest = (float *)(merged + off[7]);
-            hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, t, (long long)P, fin);
+            hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), t, (long long)P, fin);
             rc = check_launch(ctx, "acc_pack_sliced_kernel");
             if (rc) return rc;
         }
@@ -2462,7 +2578,7 @@ extern "C" int ampli_error_finalize_merged(ampli_ctx *ctx, int64_t P, const doub
     acc_offsets(P, off);
     FinOut fo = {};
     fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
-    hipLaunchKernelGGL(error_finalize_merged_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_packed,
+    hipLaunchKernelGGL(error_finalize_merged_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), d_packed,
                        (const char *)d_gm_regions, off[5] - off[4], off[6] - off[4], off[7] - off[4], (int)nparts, (long long)P, C,
                        (int)cov, fo);
     return check_launch(ctx, "error_finalize_merged_kernel");
@@ -2526,7 +2642,7 @@ extern "C" int ampli_acc_to_slices(ampli_ctx *ctx, const ampli_acc_table *d_acc,
     fo.sl_fmt = ctx->slice_fmt; fo.sl_n = n_slices; fo.sl_flags = ctx->d_flags;
     fo.sl_sums = d_sums + (size_t)ctx->grp_index * slice_planes(fo.sl_fmt) * (size_t)fo.slice_len;
     fo.sl_gm = d_gm + (size_t)ctx->grp_index * 8 * (size_t)fo.slice_len;
-    hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, fo);
+    hipLaunchKernelGGL(acc_pack_sliced_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), to_ptrs(d_acc), P, fo);
     return check_launch(ctx, "acc_pack_sliced_kernel");
 }
 
@@ -2539,7 +2655,7 @@ extern "C" int ampli_error_finalize_slice(ampli_ctx *ctx, int64_t P, int32_t n_s
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long L = ampli_slice_len(P, n_slices);
     const size_t G = (size_t)ctx->grp_size, g = (size_t)ctx->grp_index; // [group][planes][L] sums, [n][group][8][L] pairs, [group][block] out
-    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((4 * L + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(error_finalize_slice_kernel, dim3((unsigned)((4 * L + 255) / 256)), dim3(256), 0, main_stream(ctx),
                        d_sum_slice + g * (size_t)slice_planes(ctx->slice_fmt) * (size_t)L, d_gm_recv + g * 8 * (size_t)L, G * 8 * (size_t)L, (int)n_slices, L,
                        (long long)slice_index * L, (long long)P, C, (int)cov, (char *)d_block + g * slice_block_bytes(L), ctx->slice_fmt);
     return check_launch(ctx, "error_finalize_slice_kernel");
@@ -2555,7 +2671,7 @@ extern "C" int ampli_error_table_unslice(ampli_ctx *ctx, int64_t P, int32_t n_sl
     FinOut fo = {};
     fo.rate = d_rate; fo.code = d_code; fo.thr = d_thr; fo.germ_val = d_germ_val; fo.germ_present = d_germ_present; fo.flags = d_flags;
     const long long L = ampli_slice_len(P, n_slices);
-    hipLaunchKernelGGL(error_table_unslice_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(error_table_unslice_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx),
                        (const char *)d_blocks + (size_t)ctx->grp_index * slice_block_bytes(L), (size_t)ctx->grp_size * slice_block_bytes(L),
                        (int)n_slices, L, (long long)P, fo);
     return check_launch(ctx, "error_table_unslice_kernel");
@@ -2575,9 +2691,9 @@ extern "C" int ampli_acc_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, con
     AccPtrs hp[64];
     for (int i = 0; i < nparts; ++i) hp[i] = to_ptrs(&d_parts[i]);
     // small synchronous upload of the pointer list (not on a captured path)
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, hp, sizeof(AccPtrs) * nparts, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    hipLaunchKernelGGL(acc_merge_ptr_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_dst),
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->ws, hp, sizeof(AccPtrs) * nparts, hipMemcpyHostToDevice, main_stream(ctx)));
+    HIP_TRY(ctx, hipStreamSynchronize(main_stream(ctx)));
+    hipLaunchKernelGGL(acc_merge_ptr_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), to_ptrs(d_dst),
                        (const AccPtrs *)ctx->ws, (int)nparts, (long long)P);
     return check_launch(ctx, "acc_merge_ptr_kernel");
 }
@@ -2590,7 +2706,7 @@ extern "C" int ampli_acc_pack(ampli_ctx *ctx, const ampli_acc_table *d_acc, doub
     if (!d_acc || d_acc->P <= 0 || !d_packed) return fail(ctx, AMPLI_E_INVALID, "acc_pack: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long P = d_acc->P;
-    hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, d_packed);
+    hipLaunchKernelGGL(acc_pack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, main_stream(ctx), to_ptrs(d_acc), P, d_packed);
     return check_launch(ctx, "acc_pack_kernel");
 }
 
@@ -2600,7 +2716,7 @@ extern "C" int ampli_acc_unpack(ampli_ctx *ctx, const double *d_packed, const am
     if (!d_acc || d_acc->P <= 0 || !d_packed) return fail(ctx, AMPLI_E_INVALID, "acc_unpack: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const long long P = d_acc->P;
-    hipLaunchKernelGGL(acc_unpack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, ctx->stream, to_ptrs(d_acc), P, d_packed);
+    hipLaunchKernelGGL(acc_unpack_kernel, dim3((unsigned)((21 * P + 255) / 256)), dim3(256), 0, main_stream(ctx), to_ptrs(d_acc), P, d_packed);
     return check_launch(ctx, "acc_unpack_kernel");
 }
 
@@ -2623,7 +2739,7 @@ extern "C" int ampli_gm_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, cons
     const long long P = d_dst->P;
     size_t off[9];
     acc_offsets(P, off);
-    hipLaunchKernelGGL(gm_merge_kernel, dim3((unsigned)((4 * P + 255) / 256)), dim3(256), 0, ctx->stream, d_dst->gm_n,
+    hipLaunchKernelGGL(gm_merge_kernel, dim3((unsigned)((4 * P + 255) / 256)), dim3(256), 0, main_stream(ctx), d_dst->gm_n,
                        d_dst->gm_first, d_dst->gm_first_af, d_dst->gm_rest, (const char *)d_regions, off[5] - off[4],
                        off[6] - off[4], off[7] - off[4], (int)nparts, P);
     return check_launch(ctx, "gm_merge_kernel");
@@ -2647,8 +2763,98 @@ static int ensure_lgtab(ampli_ctx *ctx)
     if (ctx->d_lgtab) return AMPLI_OK;
     if (is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "the lgamma table would have to be built while capturing: run the sequence once first");
     if (hipMalloc((void **)&ctx->d_lgtab, sizeof(double) * AMPLI_LGTAB) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "lgamma table hipMalloc failed");
-    hipLaunchKernelGGL(lgamma_table_kernel, dim3((AMPLI_LGTAB + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_lgtab, AMPLI_LGTAB);
+    hipLaunchKernelGGL(lgamma_table_kernel, dim3((AMPLI_LGTAB + 255) / 256), dim3(256), 0, main_stream(ctx), ctx->d_lgtab, AMPLI_LGTAB);
     return check_launch(ctx, "lgamma_table_kernel");
+}
+
+// poisson_call, prefilter mode: poisson_stream_kernel + poisson_drain_kernel over the records [r_lo, r_hi) of every sample, on
+// `st`, with lane `lane_k`'s queue and the call list's shards [shard_lo, shard_lo + shard_n) (the whole row, lane 0 and every shard
+// unless the context runs position ranges)
+static int poisson_prefilter_launch(ampli_ctx *ctx, const int lane_k, hipStream_t st, const DevCohort &co, const int64_t P, const float *d_thr,
+                                    const long long thr_L, const size_t thr_bb, const uint8_t *d_ref_code, const int32_t cov, uint8_t *d_call_mask,
+                                    ampli_call *d_calls, const int64_t capacity, unsigned long long *d_n_calls, const long long r_lo,
+                                    const long long r_hi, const unsigned shard_lo, const unsigned shard_n)
+{
+    const int64_t E = co.E;
+    const int32_t T = co.n;
+    const uint32_t *d_ext_pos = co.ext_pos;
+    const long long R = P + E, Rk = r_hi - r_lo;
+    AmpliQueue &Q = ctx->lanes[lane_k].q;
+    // one wave per (64-record tile, rows_per_wave tumour rows), four row groups per workgroup.  Few rows per wave =
+    // many short waves that keep every CU fed through the tail; the thresholds of a tile are shared through the
+    // XCD's L2 by the mapping of poisson_stream_kernel, so short waves no longer cost re-reads over the fabric.
+    const long long tiles = (Rk + 63) / 64, tiles8 = (tiles + 7) / 8 * 8;
+    // rows per wave: long-lived waves stream best from cold HBM (config 3 in bench.py's loop: 24 rows 0.062 ms, 8 rows
+    // 0.065 ms, 4 rows 0.068 ms), as long as the launch still fills the chip: halve them while it would leave more than
+    // half of the wave slots empty (a range counts for the launch of the whole row it is a part of)
+    const long long tiles_all = (R + 63) / 64;
+    int rpw = ctx->pc_rows_per_wave > 0 ? ctx->pc_rows_per_wave : 24;
+    if (rpw > (T + 3) / 4) rpw = (T + 3) / 4;
+    if (ctx->pc_rows_per_wave <= 0)
+        while (rpw > 2 && tiles_all * 4 * ((T + 4 * rpw - 1) / (4 * rpw)) < (long long)ctx->n_cu * 16) rpw = (rpw + 1) / 2;
+    if (rpw < 1) rpw = 1;
+    long long gy = (T + 4 * rpw - 1) / (4 * rpw);
+    while (tiles8 * gy > 0x7fffffffll) { rpw *= 2; gy = (T + 4 * rpw - 1) / (4 * rpw); } // gridDim.x limit
+    // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),
+    // or what ampli_set_queue_items asked for plus one workgroup's worth of slack per shard (workgroups are dealt
+    // to the shards round-robin, so a shard holds at most ceil(blocks/SHARDS) workgroups' items)
+    size_t want = (size_t)std::max<long long>(1 << 16, (long long)T * Rk / 4);
+    const size_t slack = (size_t)AMPLI_CALL_SHARDS * 256 * 3 * (size_t)rpw;
+    if (ctx->queue_min_items) want = std::max(want, ctx->queue_min_items + slack);
+    want = (want + AMPLI_CALL_SHARDS - 1) / AMPLI_CALL_SHARDS * AMPLI_CALL_SHARDS;
+    const bool capturing = is_capturing(ctx);
+    if ((Q.n_items < want || !Q.n) && capturing)
+        return fail(ctx, AMPLI_E_INVALID, "queue would have to be allocated while capturing: run the sequence once first");
+    if (Q.n_items < want) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (Q.items) (void)hipFree(Q.items);
+        Q.items = nullptr; Q.n_items = 0;
+        if (hipMalloc(&Q.items, want * sizeof(PcItem)) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "queue hipMalloc failed");
+        Q.n_items = want;
+    }
+    if (!Q.n) {
+        if (hipMalloc((void **)&Q.n, 2 * sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS) != hipSuccess)
+            return fail(ctx, AMPLI_E_NOMEM, "queue counter hipMalloc failed");
+        HIP_TRY(ctx, hipMemsetAsync(Q.n, 0, 2 * sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, st));
+    }
+    const long long per = (long long)(Q.n_items / AMPLI_CALL_SHARDS);
+    unsigned long long *qn = Q.n + (size_t)(Q.parity & 1) * AMPLI_CALL_COUNTER_WORDS;
+    unsigned long long *qn_next = Q.n + (size_t)((Q.parity + 1) & 1) * AMPLI_CALL_COUNTER_WORDS;
+    if (capturing) // a replayed graph cannot alternate halves: reset the half it uses with a memset node instead
+        HIP_TRY(ctx, hipMemsetAsync(qn, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, st));
+    else
+        Q.parity ^= 1;
+    dim3 qgrid((unsigned)(tiles8 * gy));
+    const bool irr = co.rv.rd || co.rv.rd_ext;
+#define AMPLI_LAUNCH_STREAM_I(LV, IV)                                                                                            \
+    hipLaunchKernelGGL((poisson_stream_kernel<LV, IV>), qgrid, dim3(256), 0, st, co.rv, (long long)P,                             \
+                       (long long)E, d_ext_pos, (int)T, rpw, (unsigned)gy, d_thr, thr_L, thr_bb, d_ref_code, (int)cov,            \
+                       (PcItem *)Q.items, per, qn, d_call_mask, ctx->d_flags, d_n_calls, r_lo, r_hi, shard_lo, shard_n)
+#define AMPLI_LAUNCH_STREAM(LV) do { if (irr) AMPLI_LAUNCH_STREAM_I(LV, true); else AMPLI_LAUNCH_STREAM_I(LV, false); } while (0)
+    if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
+    else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
+    else AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_I32);
+#undef AMPLI_LAUNCH_STREAM_I
+#undef AMPLI_LAUNCH_STREAM
+    int rc = check_launch(ctx, "poisson_stream_kernel");
+    if (rc) return rc;
+    hipStream_t dstream = st;
+    if (ctx->async_drain) { // let the drain run beside whatever the caller enqueues next (never with ranges)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_stream_done, st));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_stream_done, 0));
+        dstream = ctx->side;
+    }
+    // AMPLI_CALL_SHARDS x dgy workgroups, 128 items per workgroup pass: one pass while up to ~1.4 % of the records are
+    // queued (0.2 % on the synthetic and Toy_data panels); a workgroup without items leaves after one load
+    const unsigned dgy = (unsigned)(ctx->pc_drain_blocks > 0 ? ctx->pc_drain_blocks
+                                                             : std::min<long long>(1024, std::max<long long>(16, (long long)T * Rk / 300000)));
+    hipLaunchKernelGGL(poisson_drain_kernel, dim3(AMPLI_CALL_SHARDS, dgy), dim3(256), 0, dstream, (const PcItem *)Q.items, per, qn,
+                       (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next, shard_lo, shard_n);
+    if (ctx->async_drain) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_drain_done, ctx->side));
+        ctx->drain_pending = true;
+    }
+    return check_launch(ctx, "poisson_drain_kernel");
 }
 
 static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, const float *d_thr, const long long thr_L, const size_t thr_bb,
@@ -2678,9 +2884,9 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
     const long long R = P + E;
     dim3 grid((unsigned)((R + 255) / 256), (unsigned)((T + PC_SAMPLES - 1) / PC_SAMPLES));
     if (d_n_calls && (mode == AMPLI_POISSON_FULL || d_af)) // the two-kernel path resets the counters in-kernel
-        HIP_TRY(ctx, hipMemsetAsync(d_n_calls, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(d_n_calls, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, main_stream(ctx)));
 #define AMPLI_LAUNCH_PC(MODEV, UV)                                                                                              \
-    hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                  \
+    hipLaunchKernelGGL((poisson_call_kernel<MODEV, UV>), grid, dim3(256), 0, main_stream(ctx), co.rv, (long long)P,                  \
                        (long long)E, d_ext_pos, (int)T, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, d_call_mask, d_calls,       \
                        (long long)capacity,                                                                                     \
                        d_n_calls, d_q, d_af, (const double *)ctx->d_lgtab)
@@ -2694,82 +2900,24 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
         else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_U16);
         else AMPLI_LAUNCH_PC(AMPLI_POISSON_PREFILTER, AMPLI_RECORDS_I32);
     } else {
-        // one wave per (64-record tile, rows_per_wave tumour rows), four row groups per workgroup.  Few rows per wave =
-        // many short waves that keep every CU fed through the tail; the thresholds of a tile are shared through the
-        // XCD's L2 by the mapping of poisson_stream_kernel, so short waves no longer cost re-reads over the fabric.
-        const long long tiles = (R + 63) / 64, tiles8 = (tiles + 7) / 8 * 8;
-        // rows per wave: long-lived waves stream best from cold HBM (config 3 in bench.py's loop: 24 rows 0.062 ms, 8 rows
-        // 0.065 ms, 4 rows 0.068 ms), as long as the launch still fills the chip: halve them while it would leave more than
-        // half of the wave slots empty
-        int rpw = ctx->pc_rows_per_wave > 0 ? ctx->pc_rows_per_wave : 24;
-        if (rpw > (T + 3) / 4) rpw = (T + 3) / 4;
-        if (ctx->pc_rows_per_wave <= 0)
-            while (rpw > 2 && tiles * 4 * ((T + 4 * rpw - 1) / (4 * rpw)) < (long long)ctx->n_cu * 16) rpw = (rpw + 1) / 2;
-        if (rpw < 1) rpw = 1;
-        long long gy = (T + 4 * rpw - 1) / (4 * rpw);
-        while (tiles8 * gy > 0x7fffffffll) { rpw *= 2; gy = (T + 4 * rpw - 1) / (4 * rpw); } // gridDim.x limit
-        // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),
-        // or what ampli_set_queue_items asked for plus one workgroup's worth of slack per shard (workgroups are dealt
-        // to the shards round-robin, so a shard holds at most ceil(blocks/SHARDS) workgroups' items)
-        size_t want = (size_t)std::max<long long>(1 << 16, (long long)T * R / 4);
-        const size_t slack = (size_t)AMPLI_CALL_SHARDS * 256 * 3 * (size_t)rpw;
-        if (ctx->queue_min_items) want = std::max(want, ctx->queue_min_items + slack);
-        want = (want + AMPLI_CALL_SHARDS - 1) / AMPLI_CALL_SHARDS * AMPLI_CALL_SHARDS;
-        const bool capturing = is_capturing(ctx);
-        if ((ctx->queue_items < want || !ctx->queue_n) && capturing)
-            return fail(ctx, AMPLI_E_INVALID, "queue would have to be allocated while capturing: run the sequence once first");
-        if (ctx->async_drain && capturing) return fail(ctx, AMPLI_E_INVALID, "asynchronous drain cannot be captured");
-        if (ctx->queue_items < want) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->queue) (void)hipFree(ctx->queue);
-            ctx->queue = nullptr; ctx->queue_items = 0;
-            if (hipMalloc(&ctx->queue, want * sizeof(PcItem)) != hipSuccess) return fail(ctx, AMPLI_E_NOMEM, "queue hipMalloc failed");
-            ctx->queue_items = want;
-        }
-        if (!ctx->queue_n) {
-            if (hipMalloc((void **)&ctx->queue_n, 2 * sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS) != hipSuccess)
-                return fail(ctx, AMPLI_E_NOMEM, "queue counter hipMalloc failed");
-            HIP_TRY(ctx, hipMemsetAsync(ctx->queue_n, 0, 2 * sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
-        }
         if (((uintptr_t)d_call_mask & 3) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call_mask must be 4-byte aligned");
-        const long long per = (long long)(ctx->queue_items / AMPLI_CALL_SHARDS);
-        unsigned long long *qn = ctx->queue_n + (size_t)(ctx->queue_parity & 1) * AMPLI_CALL_COUNTER_WORDS;
-        unsigned long long *qn_next = ctx->queue_n + (size_t)((ctx->queue_parity + 1) & 1) * AMPLI_CALL_COUNTER_WORDS;
-        if (capturing) // a replayed graph cannot alternate halves: reset the half it uses with a memset node instead
-            HIP_TRY(ctx, hipMemsetAsync(qn, 0, sizeof(unsigned long long) * AMPLI_CALL_COUNTER_WORDS, ctx->stream));
-        else
-            ctx->queue_parity ^= 1;
-        dim3 qgrid((unsigned)(tiles8 * gy));
-        const bool irr = co.rv.rd || co.rv.rd_ext;
-#define AMPLI_LAUNCH_STREAM_I(LV, IV)                                                                                            \
-    hipLaunchKernelGGL((poisson_stream_kernel<LV, IV>), qgrid, dim3(256), 0, ctx->stream, co.rv, (long long)P,                    \
-                       (long long)E, d_ext_pos, (int)T, rpw, (unsigned)gy, d_thr, thr_L, thr_bb, d_ref_code, (int)cov,            \
-                       (PcItem *)ctx->queue, per, qn, d_call_mask, ctx->d_flags, d_n_calls)
-#define AMPLI_LAUNCH_STREAM(LV) do { if (irr) AMPLI_LAUNCH_STREAM_I(LV, true); else AMPLI_LAUNCH_STREAM_I(LV, false); } while (0)
-        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U24);
-        else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_U16);
-        else AMPLI_LAUNCH_STREAM(AMPLI_RECORDS_I32);
-#undef AMPLI_LAUNCH_STREAM_I
-#undef AMPLI_LAUNCH_STREAM
-        int rc = check_launch(ctx, "poisson_stream_kernel");
-        if (rc) return rc;
-        hipStream_t dstream = ctx->stream;
-        if (ctx->async_drain) { // let the drain run beside whatever the caller enqueues next
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_stream_done, ctx->stream));
-            HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_stream_done, 0));
-            dstream = ctx->side;
+        if (ctx->async_drain && is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "asynchronous drain cannot be captured");
+        // position ranges on concurrent streams (ampli_set_ranges): every range behind its own error_estimate.  Only the listed-once
+        // shape: an extra occurrence reads the thresholds of a position that may belong to another range
+        const bool ranged = ranges_apply(ctx, R) && E == 0 && (R & 3) == 0 && !ctx->async_drain;
+        if (!ranged) return poisson_prefilter_launch(ctx, 0, main_stream(ctx), co, P, d_thr, thr_L, thr_bb, d_ref_code, cov, d_call_mask, d_calls, capacity, d_n_calls,
+                                                     0, R, 0, AMPLI_CALL_SHARDS);
+        { int rcf = ranges_fork(ctx, P); if (rcf) return rcf; }
+        long long cut[AMPLI_MAX_RANGES + 1];
+        range_cuts(R, ctx->n_ranges, cut);
+        for (int k = 0; k < ctx->n_ranges; ++k) {
+            const unsigned s_lo = (unsigned)(AMPLI_CALL_SHARDS * k / ctx->n_ranges), s_hi = (unsigned)(AMPLI_CALL_SHARDS * (k + 1) / ctx->n_ranges);
+            hipStream_t st = lane_stream(ctx, k);
+            int rck = poisson_prefilter_launch(ctx, k, st, co, P, d_thr, thr_L, thr_bb, d_ref_code, cov, d_call_mask, d_calls, capacity, d_n_calls,
+                                               cut[k], cut[k + 1], s_lo, s_hi - s_lo);
+            if (rck) return rck;
         }
-        // AMPLI_CALL_SHARDS x dgy workgroups, 128 items per workgroup pass: one pass while up to ~1.4 % of the records are
-        // queued (0.2 % on the synthetic and Toy_data panels); a workgroup without items leaves after one load
-        const unsigned dgy = (unsigned)(ctx->pc_drain_blocks > 0 ? ctx->pc_drain_blocks
-                                                                 : std::min<long long>(1024, std::max<long long>(16, (long long)T * R / 300000)));
-        hipLaunchKernelGGL(poisson_drain_kernel, dim3(AMPLI_CALL_SHARDS, dgy), dim3(256), 0, dstream, (const PcItem *)ctx->queue, per, qn,
-                           (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next);
-        if (ctx->async_drain) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev_drain_done, ctx->side));
-            ctx->drain_pending = true;
-        }
-        return check_launch(ctx, "poisson_drain_kernel");
+        return AMPLI_OK;
     }
     return check_launch(ctx, "poisson_call_kernel");
 }
@@ -2813,7 +2961,7 @@ extern "C" int ampli_score_batch(ampli_ctx *ctx, const int32_t *d_k, const int32
 {
     if (!ctx || !d_k || !d_rd || !d_err || n <= 0) return AMPLI_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(score_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_rd, d_err,
+    hipLaunchKernelGGL(score_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, main_stream(ctx), d_k, d_rd, d_err,
                        (long long)n, d_q, d_p);
     return check_launch(ctx, "score_batch_kernel");
 }
@@ -2823,7 +2971,7 @@ extern "C" int ampli_score_dense_batch(ampli_ctx *ctx, const int32_t *d_k, const
     if (!ctx || !d_k || !d_rd || !d_err || !d_q || n <= 0) return AMPLI_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rcl = ensure_lgtab(ctx); if (rcl) return rcl; }
-    hipLaunchKernelGGL(score_dense_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_k, d_rd, d_err,
+    hipLaunchKernelGGL(score_dense_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, main_stream(ctx), d_k, d_rd, d_err,
                        (long long)n, d_q, (const double *)ctx->d_lgtab);
     return check_launch(ctx, "score_dense_batch_kernel");
 }
@@ -2832,7 +2980,7 @@ extern "C" int ampli_roundtrip_batch(ampli_ctx *ctx, const float *d_in, int64_t 
 {
     if (!ctx || !d_in || !d_out || n <= 0) return AMPLI_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(roundtrip_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_in, (long long)n, d_out);
+    hipLaunchKernelGGL(roundtrip_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, main_stream(ctx), d_in, (long long)n, d_out);
     return check_launch(ctx, "roundtrip_batch_kernel");
 }
 
@@ -2841,7 +2989,7 @@ extern "C" int ampli_synth_fill(ampli_ctx *ctx, int32_t *d_recs, int64_t P, int3
 {
     if (!ctx || !d_recs || P <= 0 || n_samples <= 0 || n_samples > 65535 || depth <= 0) return AMPLI_E_INVALID; // n_samples = gridDim.y
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)n_samples), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)n_samples), dim3(256), 0, main_stream(ctx),
                        (int4 *)d_recs, (long long)P, (int)n_samples, (int)first_sample, (unsigned long long)seed, (int)depth, (int)tumour);
     return check_launch(ctx, "synth_fill_kernel");
 }
@@ -2852,7 +3000,7 @@ extern "C" int ampli_records_pack16(ampli_ctx *ctx, const int32_t *d_recs32, int
     if (!d_recs32 || !d_recs16 || !d_overflow || n_records <= 0 || ((uintptr_t)d_recs32 & 15) || ((uintptr_t)d_recs16 & 15))
         return fail(ctx, AMPLI_E_INVALID, "records_pack16: bad argument (16-byte aligned buffers, n_records > 0, overflow word)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(records_pack16_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, (const int4 *)d_recs32,
+    hipLaunchKernelGGL(records_pack16_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, main_stream(ctx), (const int4 *)d_recs32,
                        (long long)n_records, (uint4 *)d_recs16, d_overflow);
     return check_launch(ctx, "records_pack16_kernel");
 }
@@ -2863,7 +3011,7 @@ extern "C" int ampli_records_pack24(ampli_ctx *ctx, const int32_t *d_recs32, int
     if (!d_recs32 || !d_recs24 || !d_overflow || n_records <= 0 || ((uintptr_t)d_recs32 & 15) || ((uintptr_t)d_recs24 & 7))
         return fail(ctx, AMPLI_E_INVALID, "records_pack24: bad argument (aligned buffers, n_records > 0, overflow word)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(records_pack24_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, (const int4 *)d_recs32,
+    hipLaunchKernelGGL(records_pack24_kernel, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, main_stream(ctx), (const int4 *)d_recs32,
                        (long long)n_records, (uint2 *)d_recs24, d_overflow);
     return check_launch(ctx, "records_pack24_kernel");
 }
@@ -2872,7 +3020,7 @@ extern "C" int ampli_synth_ref(ampli_ctx *ctx, uint8_t *d_ref_code, int64_t P, u
 {
     if (!ctx || !d_ref_code || P <= 0) return AMPLI_E_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, ctx->stream, d_ref_code, (long long)P,
+    hipLaunchKernelGGL(synth_ref_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, main_stream(ctx), d_ref_code, (long long)P,
                        (unsigned long long)seed);
     return check_launch(ctx, "synth_ref_kernel");
 }

@@ -435,7 +435,7 @@ extern "C" int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const ui
 #else
     const auto kernel = pileup_count_staged_kernel;
 #endif
-    hipLaunchKernelGGL(kernel, dim3((unsigned)((n_reads + PILEUP_READS - 1) / PILEUP_READS)), dim3(256), 0, ctx->stream, (const unsigned char *)d_bam,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((n_reads + PILEUP_READS - 1) / PILEUP_READS)), dim3(256), 0, main_stream(ctx), (const unsigned char *)d_bam,
                        (const unsigned long long *)d_rec_off, (long long)n_reads, (const unsigned long long *)d_keys, (long long)P, (int)mbq, (int)mrq,
                        d_counts, (unsigned long long *)d_stats);
     return check_launch(ctx, "pileup_count_kernel");

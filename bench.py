@@ -59,8 +59,11 @@ def parse_args():
     ap.add_argument("--sustained", type=int, default=2000, help="passes of the sustained-rate block after the timed region (0 = skip)")
     ap.add_argument("--cold-batches", type=int, default=3, help="N = 1: distinct resident batches the cold-HBM block rotates over after the timed region "
                     "(no pass finds its inputs in the Infinity Cache); 0 or 1 = skip")
-    ap.add_argument("--no-split-ranges", dest="split_ranges", action="store_false", help="N = 1: skip the block that repeats the pass with the "
-                    "positions in two ranges on two streams (after the timed region)")
+    ap.add_argument("--ranges", type=int, default=2, help="N = 1: position ranges on concurrent streams INSIDE the library (ampli_set_ranges): "
+                    "error_estimate and poisson_call cut the panel into this many tile-aligned ranges, each on a stream of its own, so that "
+                    "back-to-back passes fill each other's partly filled rounds of workgroups.  1 = every launch whole, on one stream")
+    ap.add_argument("--no-split-ranges", dest="split_ranges", action="store_false", help="the same as --ranges 1: the timed region on one stream, "
+                    "per-kernel HIP events around undisturbed launches (what rounds 1-4 timed)")
     ap.add_argument("--whole-rounds", type=int, default=4, help="N = 1: after the timed region, time the dominant reduce kernel on a panel of this many "
                     "whole rounds of resident workgroups (what the partly filled last round of the configuration costs); 0 = skip")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the reference's error estimation on ALL normals of config 3 (~6 min on one core)")
@@ -510,6 +513,12 @@ def main():
         for e in ev:
             e[2] = e[1]
     ev_steps = [i for i in range(args.steps) if i % max(1, args.event_every) == 0]
+    # position ranges inside the library (N = 1): the kernels of a pass are then several launches on several streams, timed by events
+    # on each range's own stream (ampli_range_event_record: does not close the section)
+    n_ranges = args.ranges if (args.split_ranges and not multi and args.streams <= 1 and mode == POISSON_PREFILTER and not args.async_drain) else 1
+    if n_ranges > 1 and ((P + 63) // 64 < 2 * n_ranges or P % 4 != 0 or layout != "u16"):
+        n_ranges = 1  # the library would run such launches whole (include/amplisolve_hip.h, ampli_set_ranges)
+    evr = {i: [[ctx.event() for _ in range(3)] for _ in range(n_ranges)] for i in ev_steps} if n_ranges > 1 else None
 
     # two error tables, used alternately: with the asynchronous drain the survivors of batch i are still being scored
     # (reading batch i's thresholds) while batch i+1's table is being written
@@ -522,10 +531,17 @@ def main():
     def reduce_part(i, timed, slot):
         nonlocal fin
         timed = timed and i % max(1, args.event_every) == 0
-        if timed:
+        if timed and n_ranges > 1:
+            for k in range(n_ranges):
+                ctx.range_record(k, evr[i][k][0])
+        elif timed:
             ctx.record(ev[i][0])
         if not multi:  # the panel lives on one device: finalize fused into the reduce epilogue (ampli_error_estimate)
             fins[i & 1] = fin = ctx.error_estimate(normals, P, 0.002, 100, out=fins[i & 1])
+            if timed and n_ranges > 1:
+                for k in range(n_ranges):
+                    ctx.range_record(k, evr[i][k][1])
+                return
         elif sliced:  # shard of a multi-GPU panel: sums and germ-max pairs straight into the slice-major exchange buffers
             ctx.error_reduce_sliced(normals, P, world, merger.sums[slot], merger.gm[slot], 0.002, 100, first_sample=s_lo)
         else:  # shard of a multi-GPU panel: sums straight into the all-reduce buffer, gm planes into the table
@@ -553,7 +569,10 @@ def main():
             ctx.record(ev[i][2])
         ctx.poisson_call(tumours, P, fin.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap,
                          calls_buf=calls_buf, n_calls=n_calls)
-        if timed:
+        if timed and n_ranges > 1:
+            for k in range(n_ranges):
+                ctx.range_record(k, evr[i][k][2])
+        elif timed:
             ctx.record(ev[i][3])
 
     def run_steps(n, timed):
@@ -675,6 +694,8 @@ def main():
             sliced = False
             args.merge = "allreduce"
             merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack)
+    if n_ranges > 1:
+        ctx.set_ranges(n_ranges)
     run_steps(args.warmup, False)
     fence()
     if sliced and slim:
@@ -730,8 +751,24 @@ def main():
     kflags = ctx.flags(clear=True)
     if kflags != 0:  # AMPLI_FLAG_QUEUE_OVERFLOW / AMPLI_FLAG_RERUN_GENERAL: the passes just timed were not full passes
         raise SystemExit(f"rank {rank}: kernel flags {kflags:#x} were raised inside the timed region; the measurement is void")
-    t_red = sum(ctx.elapsed_ms(ev[i][0], ev[i][1]) for i in ev_steps) / len(ev_steps)
-    t_call_main = sum(ctx.elapsed_ms(ev[i][2], ev[i][3]) for i in ev_steps) / len(ev_steps)  # main-stream part (all of it unless --async-drain)
+    ranges_block = None
+    if n_ranges > 1:
+        # per range and kernel, under the overlap the ranges exist for: events on the range's own stream.  A launch's duration is then
+        # that of a kernel sharing the chip with the other ranges' kernels; their mean is what `rocprofv3 --stats` averages too.
+        tiles_all = (P + 63) // 64
+        cuts = [min(P, (tiles_all * k // n_ranges) * 64) for k in range(n_ranges)] + [P]
+        r_red = [sum(ctx.elapsed_ms(evr[i][k][0], evr[i][k][1]) for i in ev_steps) / len(ev_steps) for k in range(n_ranges)]
+        r_call = [sum(ctx.elapsed_ms(evr[i][k][1], evr[i][k][2]) for i in ev_steps) / len(ev_steps) for k in range(n_ranges)]
+        t_red, t_call_main = sum(r_red) / n_ranges, sum(r_call) / n_ranges  # mean launch (each launch = 1 / n of the panel)
+        ranges_block = {"n": n_ranges, "positions": [cuts[k + 1] - cuts[k] for k in range(n_ranges)], "error_reduce_ms": r_red, "poisson_call_ms": r_call,
+                        "note": "ampli_set_ranges: every range's error_estimate + poisson_call on a stream of its own inside the library; durations by "
+                                "events on the range's stream (ampli_range_event_record), i.e. of launches that share the chip with the other ranges'"}
+        # the outputs the ranges left behind (last pass of the timed region), to be compared with the one-stream pass's below
+        ranged_out = (fin.thr.clone(), fin.code.clone(), fin.germ_present.clone(), call_mask.clone(), int(n_calls[::CALL_COUNTER_STRIDE].sum().item()))
+        ctx.set_ranges(1)  # everything below times whole launches on one stream
+    else:
+        t_red = sum(ctx.elapsed_ms(ev[i][0], ev[i][1]) for i in ev_steps) / len(ev_steps)
+        t_call_main = sum(ctx.elapsed_ms(ev[i][2], ev[i][3]) for i in ev_steps) / len(ev_steps)  # main-stream part (all of it unless --async-drain)
     ctx.wait_calls()
     if lanes is not None:
         n_calls, fin = lanes[0][2]["n_calls"], lanes[0][1]
@@ -932,74 +969,41 @@ def main():
             whole_rounds = {"error": f"{type(exc).__name__}: {exc}"}
             print(f"bench.py: the whole_rounds block failed: {exc}", file=sys.stderr)
 
-    # The same pass with the panel's positions cut into two tile-aligned ranges, each range on a stream of its own (own context,
-    # own outputs; the inputs are views of the same resident batch): the second range's error_reduce and the first range's
-    # poisson_call fill the thin last round of workgroups that a single launch of config 3 ends with.
-    # Same results, position for position.  Outside the contract's timed region, which stays one stream so that the kernel
-    # durations of `roofline` are those of undisturbed launches; `--ranges 2` is not needed to get this block.
-    two_ranges = None
-    if not multi and lanes is None and args.split_ranges and mode == POISSON_PREFILTER and P >= 4096:
+    # With position ranges in the timed region, the same pass once more WITHOUT them: every launch whole, on one stream, HIP events
+    # around every kernel of every pass -- what rounds 1-4 timed, and the undisturbed kernel durations beside the overlapped ones.
+    one_stream = None
+    if n_ranges > 1:
         try:
-            cut = ((P + 63) // 64 // 2) * 64
-            relem = {"i32": 8, "u16": 8, "u24": 24}[layout]
-            nv, tv = normals.view(S, P, relem), tumours.view(T, P, relem)
-            parts = []
-            for lo, hi in ((0, cut), (cut, P)):
-                st = torch.cuda.Stream(device=dev_index)
-                with torch.cuda.stream(st):
-                    c = Context(dev_index)
-                    c.set_record_layout(layout)
-                    nrec = c.records(nv[:, lo:hi], layout, S, row_stride=P)
-                    trec = c.records(tv[:, lo:hi], layout, T, row_stride=P)
-                    rc = ref_code[lo:hi].contiguous()
-                    f = c.error_reduce_records(nrec, hi - lo, None, finalize=True)
-                    r = c.poisson_call_records(trec, hi - lo, f.thr, rc, 100, capacity=cap)
-                parts.append(dict(c=c, st=st, n=hi - lo, nrec=nrec, trec=trec, rc=rc, f=f, r=r))
-            torch.cuda.synchronize()
-
-            def part_step(q):
-                q["c"].error_reduce_records(q["nrec"], q["n"], None, out=q["f"], finalize=True)
-                q["c"].poisson_call_records(q["trec"], q["n"], q["f"].thr, q["rc"], 100, call_mask=q["r"]["call_mask"], capacity=q["r"]["capacity"],
-                                            calls_buf=q["r"]["calls_buf"], n_calls=q["r"]["n_calls"])
-
+            ev1 = [[ctx.event() for _ in range(3)] for _ in range(args.steps)]
             for _ in range(max(2, args.warmup)):
-                for q in parts:
-                    part_step(q)
+                local_step()
             torch.cuda.synchronize()
-            cur = torch.cuda.current_stream()
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ea.record(cur)
-            for q in parts:
-                q["st"].wait_event(ea)
-            for _ in range(args.steps):
-                for q in parts:
-                    part_step(q)
-            for q in parts:
-                cur.wait_stream(q["st"])
-            eb.record(cur)
+            f1 = fins[0]
+            for i in range(args.steps):
+                ctx.record(ev1[i][0])
+                ctx.error_estimate(normals, P, 0.002, 100, out=f1)
+                ctx.record(ev1[i][1])
+                ctx.poisson_call(tumours, P, f1.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
+                ctx.record(ev1[i][2])
             torch.cuda.synchronize()
-            ms2 = ea.elapsed_time(eb) / args.steps
-            # against the single-stream pass over the whole panel (the timed region's own outputs)
-            f1 = ctx.error_estimate(normals, P, 0.002, 100)
-            r1 = ctx.poisson_call(tumours, P, f1.thr, ref_code, 100, mode=mode, capacity=cap)
-            torch.cuda.synchronize()
-            same2 = all(torch.equal(torch.cat([getattr(q["f"], k) for q in parts], dim=-1).view(torch.uint8), getattr(f1, k).view(torch.uint8))
-                        for k in ("rate", "thr", "code", "germ_present"))
-            same2 = same2 and torch.equal(torch.cat([q["r"]["call_mask"] for q in parts], dim=1), r1["call_mask"])
-            same2 = same2 and sum(q["c"].n_calls_total(q["r"]) for q in parts) == ctx.n_calls_total(r1)
-            bad2 = any(q["c"].flags(clear=True) != 0 for q in parts)
-            two_ranges = {"positions": [cut, P - cut], "streams": 2, "steps": args.steps, "ms_per_step": ms2, "value": (P * S + P * T) / (ms2 * 1e-3),
-                          "same_outputs": bool(same2) and not bad2,
-                          "note": "the pass of the timed region with its positions in two ranges on two streams (kernels of one range fill the other's "
-                                  "partly filled rounds); events around the whole run on a parent stream; outputs compared with the single-stream pass"}
-            if bad2:
-                raise SystemExit("kernel flags raised in the two-ranges block")
-            for q in parts:
-                q["c"].close()
-            del parts, f1, r1
+            ms1 = ctx.elapsed_ms(ev1[0][0], ev1[-1][2]) / args.steps
+            red1 = sum(ctx.elapsed_ms(e[0], e[1]) for e in ev1) / args.steps
+            call1 = sum(ctx.elapsed_ms(e[1], e[2]) for e in ev1) / args.steps
+            rb1, cb1 = rec_bytes * P * S + 88 * P, rec_bytes * P * T + 33 * P + P * T
+            same1 = (torch.equal(ranged_out[0].view(torch.int32), f1.thr.view(torch.int32)) and torch.equal(ranged_out[1], f1.code) and
+                     torch.equal(ranged_out[2], f1.germ_present) and torch.equal(ranged_out[3], call_mask) and
+                     ranged_out[4] == int(n_calls[::CALL_COUNTER_STRIDE].sum().item()))
+            del ranged_out
+            one_stream = {"steps": args.steps, "ms_per_step": ms1, "same_outputs_as_the_timed_region": bool(same1), "value": (P * S + P * T) / (ms1 * 1e-3), "kernel": ctx.last_reduce_kernel(),
+                          "error_reduce_ms": red1, "error_reduce_frac_of_peak": rb1 / (red1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "poisson_call_ms": call1, "poisson_call_frac_of_peak": cb1 / (call1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "note": "the pass of the timed region without position ranges (ampli_set_ranges(1)): whole launches on one stream, HIP events around "
+                                  "every kernel of every pass (the events cost a few us per pass); after the timed region"}
+            if ctx.flags(clear=True) != 0:
+                raise SystemExit("kernel flags raised in the one-stream block")
         except (Exception, SystemExit) as exc:  # an extra block must not cost the run its line: the failure is reported in its place
-            two_ranges = {"error": f"{type(exc).__name__}: {exc}"}
-            print(f"bench.py: the two_ranges block failed: {exc}", file=sys.stderr)
+            one_stream = {"error": f"{type(exc).__name__}: {exc}"}
+            print(f"bench.py: the one_stream block failed: {exc}", file=sys.stderr)
 
     others = []
     for name in [n for n in ("i32", "u24", "u16") if n in packed and n != layout and not multi and lanes is None]:
@@ -1051,6 +1055,9 @@ def main():
         red_name = ctx.last_reduce_kernel()
         if red_name == "error_reduce_kernel":
             red_name = f"error_reduce_kernel<true, 1, {lay}>"
+        # with position ranges a kernel is n launches per pass, each over 1 / n of the panel (t_red / t_call are the mean launch's)
+        pass_red_bytes, pass_call_bytes = red_bytes, call_bytes
+        red_bytes, call_bytes = red_bytes / n_ranges, call_bytes / n_ranges
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = red_name, t_red, red_bytes
         else:
@@ -1097,6 +1104,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "normals_total": S_total, "tumours_total": T_total, "depth": depth,
                        "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if not multi else 1,
+                       "position_ranges": n_ranges,
                        "parallelism": f"tumour+normal sample shards x{world} ({'the fixed job split' if cfg['strong'] else 'one shard of the configuration per GPU'})" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table -- one round of collectives per group of independent batches, three groups in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if multi else ""),
                        "merge": (args.merge if multi else None), "batches_per_exchange": (G if sliced else None),
                        "rehearsal": ("N>1 code path forced on one rank (--force-dist)" if args.force_dist and world == 1 else None),
@@ -1105,8 +1113,16 @@ def main():
                                        "packer uploads for the same cohort (csrc/host/aseq.cpp; e2e block: error_estimation.record_array_MB)"
                                        if args.records == "auto" else "--records given")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
-                         "traffic_source": traffic_src},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic / n_ranges if traffic else None), "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
+                         "traffic_source": traffic_src, "launches_per_step": n_ranges,
+                         "overlapped": (f"{n_ranges} launches per pass on {n_ranges} streams (ampli_set_ranges), each over 1/{n_ranges} of the panel and sharing the chip "
+                                        "with the other ranges' kernels: a launch's duration is not that of the kernel alone (one_stream block) and the "
+                                        "fractions of concurrent kernels add up (roofline_pass)") if n_ranges > 1 else None},
+            # every kernel of a pass together: algorithmic bytes of the pass / time per pass over the timed region -- the figure that
+            # is well defined when kernels of different ranges overlap
+            "roofline_pass": {"bound": "hbm", "algorithmic_bytes": pass_red_bytes + pass_call_bytes, "ms": ms_per_step,
+                              "achieved": (pass_red_bytes + pass_call_bytes) / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": (pass_red_bytes + pass_call_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "roofline_other_kernel": {"bound": "hbm", "kernel": oth, "achieved": oth_bytes / (oth_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": oth_bytes / (oth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": oth_traffic, "avg_ms": oth_ms,
                                       "algorithmic_bytes": oth_bytes},
@@ -1147,8 +1163,10 @@ def main():
             out["cold_hbm"] = cold
         if whole_rounds:
             out["roofline_whole_rounds"] = whole_rounds
-        if two_ranges:
-            out["two_ranges"] = two_ranges
+        if ranges_block:
+            out["ranges"] = ranges_block
+        if one_stream:
+            out["one_stream"] = one_stream
         if multi:
             out["communication"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "merge": args.merge,
                                     "local_step_ms": t_local_ms, "exposed_ms_per_step": max(0.0, ms_per_step - t_local_ms),

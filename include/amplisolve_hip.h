@@ -486,6 +486,31 @@ int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
  * (compact state); AMPLI_E_INVALID before the first launch.  For tests and the bench line, which name the kernel they measured. */
 int ampli_last_reduce_kernel(const ampli_ctx *ctx);
 
+/*
+ * Position ranges on concurrent streams (round 5).  A resident panel is rarely a whole number of rounds of workgroups (config 3:
+ * 1563 tiles of 64 positions on 1280 resident workgroups of error_reduce), and a launch's partly filled last round runs at a
+ * fraction of the chip.  With n_ranges > 1 (at most 4) ampli_error_estimate / ampli_error_reduce_records and ampli_poisson_call /
+ * _records (prefilter mode) cut the panel into n tile-aligned ranges of positions: range 0 runs on the context's stream, range k on
+ * a stream the context owns, each range's poisson_call behind its own error_estimate (a position's thresholds are all a
+ * record of that position needs).  Over BACK-TO-BACK passes on independent batches one range's poisson_call and another's
+ * error_reduce then fill each other's thin rounds (config 3: 0.146 -> 0.12-0.13 ms per pass); a single pass gains nothing -- the
+ * join at its end costs what the overlap inside it saves -- so the command lines do not use it.  Outputs are the same arrays,
+ * bit for bit; the call list's shards are dealt to the ranges (range k appends to shards [32 k / n, 32 (k + 1) / n)), so a shard
+ * fills n times faster than without ranges.
+ * Semantics: the section opens at the first such call (the ranges' streams wait for everything enqueued on the context's stream
+ * so far) and CLOSES -- the context's stream waits for every range -- at the next call of any other entry point on the context
+ * (ampli_sync, copies, ampli_event_record, ampli_ctx_flags, every other kernel, ampli_stream), or at ampli_ranges_join.  While
+ * it is open the caller must not enqueue work of its own that writes the ranges' inputs or reads their outputs.  Launches outside
+ * the shape (positions listed more than once, another record layout than the compact kernel's for error_estimate, the all-scores
+ * mode, a panel of fewer than 2 n tiles, P + E not a multiple of 4 for poisson_call, stream capture) simply run unsplit, after a join.
+ */
+int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges);
+int ampli_ranges_join(ampli_ctx *ctx);
+/* An event (ampli_event_create) on range `range`'s stream WITHOUT closing the section: events recorded before and after a call
+ * bracket that range's share of it -- the kernels' durations under the overlap the ranges exist for.  (ampli_event_record is an
+ * ordinary call: it closes the section first and records on the context's stream.) */
+int ampli_range_event_record(ampli_ctx *ctx, int32_t range, void *ev);
+
 /* poisson_call (prefilter mode) launch shape; 0 = default for each.  rows_per_wave: tumour rows one wave streams
  * (a workgroup = 4 waves over one 64-record tile and 4 * rows_per_wave rows).  drain_blocks_per_shard: workgroups per
  * queue shard in the drain launch.  Results do not depend on either. */

@@ -50,7 +50,7 @@ def test_rccl_calls_of_the_sliced_merge_on_a_size_one_communicator():
 
 def test_bench_line_at_one_gpu_has_the_contract_fields():
     """`python bench.py` (N = 1) on the small configuration: ONE JSON line with the contract's fields, the roofline of the dominant
-    kernel, and the self-checks of the blocks behind the timed region (layouts, position ranges on two streams) all true."""
+    kernel, and the self-checks of the blocks behind the timed region (layouts, the one-stream pass against the ranges') all true."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-e2e",
            "--sustained", "40", "--cold-batches", "2", "--whole-rounds", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -68,5 +68,10 @@ def test_bench_line_at_one_gpu_has_the_contract_fields():
     assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "traffic" in rf and 0 < rf["frac"] < 1
     assert all(x["same_outputs"] for x in d["other_record_layouts"])
-    assert d["two_ranges"]["same_outputs"] is True and d["roofline_whole_rounds"]["frac"] > 0
+    assert d["roofline_whole_rounds"]["frac"] > 0
+    # config 2 is 157 tiles: two ranges of >= 2 tiles apply; the timed region ran them inside the library, the block behind it repeats the
+    # pass on one stream and compares the outputs
+    assert d["config"]["position_ranges"] == 2 and d["ranges"]["n"] == 2 and len(d["ranges"]["error_reduce_ms"]) == 2
+    assert d["one_stream"]["same_outputs_as_the_timed_region"] is True and d["roofline"]["launches_per_step"] == 2
+    assert 0 < d["roofline_pass"]["frac"] < 1
     assert d["sustained"]["passes"] == 40 and d["cold_hbm"]["batches"] == 2

@@ -317,3 +317,87 @@ def test_position_ranges_on_two_streams_equal_the_single_pass(ctx16, P, S, T, cu
     for c, _, _ in parts:
         assert c.flags() == 0
         c.close()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4])
+@pytest.mark.parametrize("P,S,T", [(5000, 24, 6), (20000, 64, 8), (100_000, 32, 12), (520, 9, 3)])
+def test_position_ranges_inside_the_library(ctx16, P, S, T, n):
+    """The shipped form of the range split (ampli_set_ranges, round 5): ampli_error_estimate and ampli_poisson_call cut the panel into
+    n tile-aligned ranges on n streams inside the library -- the same output arrays, the call list's shards dealt to the ranges.
+    Three passes back to back (the section stays open across them), then one joining call: error table, call mask and call list of
+    the unsplit pass, bit for bit, which are the oracle's.  uint16 records take the range path; 24-byte records run unsplit behind
+    a join (the reduce) and split (the call), which must give the same again."""
+    import torch
+
+    lay = ctx16.layout_name
+    recs, trecs = synth_recs(P, S), synth_recs(P, T, tumour=True)
+    rng = np.random.default_rng(P + S + T + n)
+    e = edge_case_recs(P, S, rng)
+    pick = rng.random((S, P)) < 0.2
+    recs[pick] = e[pick]
+    ref = synth_ref(P)
+    nd, td, rd = to16(ctx16, recs), to16(ctx16, trecs), _t(ref)
+    want = orc.error_finalize(orc.error_reduce(recs, P, 0.002, 100))
+    ctx16.set_tuning(1, groups=1)  # the compact kernel's shape also for the small panels of this test
+    try:
+        whole = ctx16.error_estimate(nd, P, 0.002, 100)
+        assert_final_equal(whole, want)
+        wres = ctx16.poisson_call(td, P, whole.thr, rd, 100, capacity=1 << 16)
+        wcalls = ctx16.read_calls(wres)
+        ctx16.set_ranges(n)
+        fin = ctx16.error_estimate(nd, P, 0.002, 100)
+        res = ctx16.poisson_call(td, P, fin.thr, rd, 100, capacity=1 << 16)
+        ev = [[ctx16.event() for _ in range(3)] for _ in range(n)]
+        for it in range(2):  # the same buffers again, no join in between: each range's stream keeps its own order
+            for k in range(n):
+                ctx16.range_record(k, ev[k][0])
+            ctx16.error_estimate(nd, P, 0.002, 100, out=fin)
+            for k in range(n):
+                ctx16.range_record(k, ev[k][1])
+            ctx16.poisson_call(td, P, fin.thr, rd, 100, call_mask=res["call_mask"], capacity=res["capacity"], calls_buf=res["calls_buf"], n_calls=res["n_calls"])
+            for k in range(n):
+                ctx16.range_record(k, ev[k][2])
+        if (P + 63) // 64 >= 2 * n:  # every range's share of the call took time on its own stream (the reduce only splits uint16 records)
+            assert all(ctx16.elapsed_ms(ev[k][1], ev[k][2]) > 0 for k in range(n))
+            if lay == "u16":
+                assert all(ctx16.elapsed_ms(ev[k][0], ev[k][1]) > 0 for k in range(n))
+        assert ctx16.flags() == 0  # joins
+        for k in ("rate", "thr", "code", "germ_present", "germ_val"):
+            assert torch.equal(getattr(fin, k).view(torch.uint8), getattr(whole, k).view(torch.uint8)), k
+        assert torch.equal(res["call_mask"], wres["call_mask"])
+        key = lambda c: (c["sample"], c["record"], c["alt"])
+        got = ctx16.read_calls(res)
+        assert sorted(map(key, got)) == sorted(map(key, wcalls)) and len(got) == ctx16.n_calls_total(res)
+        assert [(c["q_fw"], c["q_bw"], c["af"]) for c in sorted(got, key=key)] == [(c["q_fw"], c["q_bw"], c["af"]) for c in sorted(wcalls, key=key)]
+    finally:
+        ctx16.set_ranges(1)
+        ctx16.set_tuning(0)
+
+
+def test_ranges_leave_other_shapes_alone(ctx16):
+    """Launches outside the range shape run unsplit behind a join: positions listed more than once, a row length that is not a
+    multiple of 4, the all-scores mode -- same results as a context without ranges."""
+    import torch
+
+    from amplisolve_amd.api import POISSON_FULL
+
+    P, S, T, E = 4099, 12, 5, 0
+    recs, trecs = synth_recs(P, S), synth_recs(P, T, tumour=True)
+    ref = synth_ref(P)
+    nd, td, rd = to16(ctx16, recs), to16(ctx16, trecs), _t(ref)
+    ctx16.set_tuning(1, groups=1)
+    try:
+        whole = ctx16.error_estimate(nd, P, 0.002, 100)
+        wres = ctx16.poisson_call(td, P, whole.thr, rd, 100, capacity=1 << 16)
+        wfull = ctx16.poisson_call(td, P, whole.thr, rd, 100, mode=POISSON_FULL, capacity=1 << 16)
+        ctx16.set_ranges(2)
+        fin = ctx16.error_estimate(nd, P, 0.002, 100)  # split (uint16) or not (24-byte records)
+        res = ctx16.poisson_call(td, P, fin.thr, rd, 100, capacity=1 << 16)  # P + E = 4099 is not a multiple of 4: unsplit, behind a join
+        full = ctx16.poisson_call(td, P, fin.thr, rd, 100, mode=POISSON_FULL, capacity=1 << 16)
+        assert ctx16.flags() == 0
+        assert torch.equal(fin.thr.view(torch.int32), whole.thr.view(torch.int32))
+        assert torch.equal(res["call_mask"], wres["call_mask"]) and torch.equal(full["call_mask"], wfull["call_mask"])
+        assert ctx16.n_calls_total(res) == ctx16.n_calls_total(wres)
+    finally:
+        ctx16.set_ranges(1)
+        ctx16.set_tuning(0)
