@@ -41,6 +41,8 @@ CONFIGS = {
     "c4": dict(P=100_000, S=1024, T=1024, depth=2000, strong=True, name="synthetic 100k positions x 1024 normals x 1024 tumours, split over the GPUs"),
     # BASELINE configs[4]: 1 M positions x 256 normals at 50 000x (T is not given there: 64 = 8 per GPU at N = 8); the
     # depth does not fit uint16, so --records auto holds it in 24-byte records; the fixed job is split over the GPUs (strong)
+    # a strong-scaling job small enough for tests of the N > 1 line (not a BASELINE configuration)
+    "c4s": dict(P=20_000, S=64, T=64, depth=2000, strong=True, name="test job: 20k positions x 64 normals x 64 tumours, split over the GPUs"),
     "c5": dict(P=1_000_000, S=256, T=64, depth=50_000, strong=True, name="synthetic 1M positions x 256 normals x 64 tumours, depth 50000x (VAF 1% stress), split over the GPUs"),
 }
 
@@ -847,6 +849,22 @@ def main():
             coll_ms = merger.time_collectives(10)
             coll_bytes = merger.bytes_received_per_step()
             fence()
+        # north_star words its scaling target on the TUMOUR SHARD ("tumour files sharded across the GPUs as embarrassingly-parallel work",
+        # ">= 0.95 strong scaling of R_VC"): poisson_call of the rank's own T / N tumours against the finished table, no
+        # exchange in it -- every rank times its shard (nothing else in flight), the slowest one counts
+        tumour_shard = None
+        if cfg["strong"]:
+            fs = fins[0] if fins[0] is not None else fin
+
+            def shard_call():
+                ctx.poisson_call(tumours, P, fs.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
+
+            fence()
+            ms_sh, _ = timed_passes(shard_call, 10)
+            tsh = torch.tensor([ms_sh], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
+            tumour_shard = {"tumours_per_gpu": T, "poisson_call_ms_slowest_rank": float(tsh.item()), "R_VC_evals_per_s": P * T_total / (float(tsh.item()) * 1e-3)}
+            fence()
         if cfg["strong"] and not args.no_strong_base:
             # The SAME job on ONE GPU, timed by rank 0 while the others wait: the base the driver's 1-GPU run cannot be (that
             # run is config 3, this job is config 4), so that every N > 1 line carries its own speed-up and efficiency.
@@ -865,8 +883,15 @@ def main():
                     ctx.poisson_call(at, P, f1.thr, ref_code, 100, mode=mode, call_mask=mask1, capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
 
                 ms1, _ = timed_passes(whole_job, 10)
+                # ... and the calling half alone: all T tumours of the job on this one GPU (the base of tumour_shard)
+                ms1_vc, _ = timed_passes(lambda: ctx.poisson_call(at, P, f1.thr, ref_code, 100, mode=mode, call_mask=mask1, capacity=cap, calls_buf=calls_buf,
+                                                                  n_calls=n_calls), 10)
                 if ctx.flags(clear=True) != 0:
                     raise SystemExit("kernel flags raised in the one-GPU base of the strong-scaling job")
+                if tumour_shard:
+                    tumour_shard.update({"one_gpu_poisson_call_ms": ms1_vc, "one_gpu_R_VC_evals_per_s": P * T_total / (ms1_vc * 1e-3),
+                                         "speedup": ms1_vc / tumour_shard["poisson_call_ms_slowest_rank"],
+                                         "efficiency": ms1_vc / tumour_shard["poisson_call_ms_slowest_rank"] / world})
                 strong_base = {"n_gpus": 1, "ms_per_step": ms1, "value": (P * S_total + P * T_total) / (ms1 * 1e-3), "passes": 10,
                                "note": "the whole job (all normals, all tumours of the configuration) on rank 0's GPU alone, after the timed "
                                        "region, HIP events around 10 passes; same kernels, same record layout"}
@@ -1055,9 +1080,29 @@ def main():
         red_name = ctx.last_reduce_kernel()
         if red_name == "error_reduce_kernel":
             red_name = f"error_reduce_kernel<true, 1, {lay}>"
-        # with position ranges a kernel is n launches per pass, each over 1 / n of the panel (t_red / t_call are the mean launch's)
+        # With position ranges in the timed region a kernel is n launches per pass on n streams, each over 1 / n of the panel and sharing
+        # the chip with the other ranges' kernels: such a launch's duration is not the kernel's (the fractions of concurrent kernels add
+        # up: roofline_pass).  The roofline of the dominant KERNEL is therefore taken on whole, undisturbed launches: the one_stream block,
+        # i.e. the same passes of this same process right behind the timed region, ranges off, HIP events around every launch -- what
+        # `rocprofv3 --stats -- python bench.py --ranges 1` averages.  The overlapped launches are in roofline_overlapped / `ranges`.
         pass_red_bytes, pass_call_bytes = red_bytes, call_bytes
-        red_bytes, call_bytes = red_bytes / n_ranges, call_bytes / n_ranges
+        overlapped = None
+        roof_measured = "HIP events on the launch stream over the timed region"
+        if n_ranges > 1:
+            overlapped = {"launches_per_step": n_ranges, "error_reduce": {"avg_ms": t_red, "algorithmic_bytes": red_bytes / n_ranges,
+                                                                          "frac": red_bytes / n_ranges / (t_red * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "poisson_call": {"avg_ms": t_call, "algorithmic_bytes": call_bytes / n_ranges,
+                                           "frac": call_bytes / n_ranges / (t_call * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "note": f"the timed region's own launches: {n_ranges} per kernel and pass on {n_ranges} streams (ampli_set_ranges), events on each range's stream; "
+                                  "a launch shares the chip with the other ranges' kernels, so these fractions are shares, not kernel efficiencies"}
+            if one_stream and "error_reduce_ms" in one_stream:
+                t_red, t_call = one_stream["error_reduce_ms"], one_stream["poisson_call_ms"]
+                roof_measured = ("HIP events around every launch of the one_stream block: the timed region's passes repeated right behind it with "
+                                 "position ranges off (whole launches on one stream); the timed region itself runs the kernels as overlapping range "
+                                 "launches (roofline_overlapped, roofline_pass)")
+            else:  # no undisturbed measurement: the overlapped launches it is
+                red_bytes, call_bytes = red_bytes / n_ranges, call_bytes / n_ranges
+                roof_measured = "HIP events on each range's stream over the timed region (overlapping launches; the one_stream block failed)"
         if t_red >= t_call:
             dom, dom_ms, dom_bytes = red_name, t_red, red_bytes
         else:
@@ -1113,11 +1158,9 @@ def main():
                                        "packer uploads for the same cohort (csrc/host/aseq.cpp; e2e block: error_estimation.record_array_MB)"
                                        if args.records == "auto" else "--records given")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": (traffic / n_ranges if traffic else None), "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
-                         "traffic_source": traffic_src, "launches_per_step": n_ranges,
-                         "overlapped": (f"{n_ranges} launches per pass on {n_ranges} streams (ampli_set_ranges), each over 1/{n_ranges} of the panel and sharing the chip "
-                                        "with the other ranges' kernels: a launch's duration is not that of the kernel alone (one_stream block) and the "
-                                        "fractions of concurrent kernels add up (roofline_pass)") if n_ranges > 1 else None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
+                         "traffic_source": traffic_src, "measured": roof_measured},
+            "roofline_overlapped": overlapped,
             # every kernel of a pass together: algorithmic bytes of the pass / time per pass over the timed region -- the figure that
             # is well defined when kernels of different ranges overlap
             "roofline_pass": {"bound": "hbm", "algorithmic_bytes": pass_red_bytes + pass_call_bytes, "ms": ms_per_step,
@@ -1180,6 +1223,15 @@ def main():
                                             "timed region); exposed = ms_per_step - local_step; collective_ms_per_round: each collective alone, 10 rounds "
                                             "back to back after the timed region (one round serves batches_per_round batches); world_size and backend as "
                                             "torch.distributed reports them (nccl = RCCL)"}
+            if tumour_shard:
+                tumour_shard["note"] = ("strong scaling of the tumour shard alone (R_VC, no exchange step): poisson_call of each rank's T / N tumours, 10 calls "
+                                        "back to back with nothing else in flight, the slowest rank's time, against the same call over all T tumours on rank "
+                                        "0's GPU alone; unverified on more than one GPU until a SCALE run exists")
+                out["tumour_shard"] = tumour_shard
+                out["tumour_shard_efficiency"] = tumour_shard.get("efficiency")
+            if strong_base and single_batch_ms:
+                # one cohort, nothing to pipeline against: the unpipelined latency of a batch against the same job on one GPU
+                out["single_cohort_efficiency"] = strong_base["ms_per_step"] / single_batch_ms / world
             if strong_base:
                 out["strong_base"] = strong_base
                 out["strong_base_value"] = strong_base["value"]

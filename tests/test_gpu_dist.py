@@ -37,6 +37,24 @@ def test_bench_multirank_path_on_one_gpu(world, merge, group):
     assert d["config"]["merge"] == merge
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_strong_scaling_line_reports_the_tumour_shard(world):
+    """The N > 1 line of a strong-scaling job (a small one: c4s; gloo ranks sharing the GPU) carries what north_star's scaling target is
+    worded on -- the tumour shard's own R_VC against all tumours on one GPU (no exchange in it) -- beside the whole-step efficiency and
+    the single-cohort (unpipelined) one."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "8", "--warmup", "3",
+           "--backend", "gloo", "--check", "--config", "c4s"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["efficiency"] > 0 and d["strong_base"]["value"] > 0
+    ts = d["tumour_shard"]
+    assert ts["tumours_per_gpu"] in (64 // world, 64 // world + 1) and ts["poisson_call_ms_slowest_rank"] > 0 and ts["one_gpu_poisson_call_ms"] > 0
+    assert abs(ts["efficiency"] - ts["one_gpu_poisson_call_ms"] / ts["poisson_call_ms_slowest_rank"] / world) < 1e-9 and d["tumour_shard_efficiency"] == ts["efficiency"]
+    assert d["single_cohort_efficiency"] > 0 and d["communication"]["single_batch_latency_ms"] > 0
+
+
 def test_rccl_calls_of_the_sliced_merge_on_a_size_one_communicator():
     """The native path of dist.SlicedMerger (reduce_scatter_tensor f64, all_to_all_single f32, all_gather_into_tensor u8)
     on a real RCCL communicator -- of size 1, all a one-GPU box offers -- in the bench's pipeline shape, with
@@ -72,6 +90,7 @@ def test_bench_line_at_one_gpu_has_the_contract_fields():
     # config 2 is 157 tiles: two ranges of >= 2 tiles apply; the timed region ran them inside the library, the block behind it repeats the
     # pass on one stream and compares the outputs
     assert d["config"]["position_ranges"] == 2 and d["ranges"]["n"] == 2 and len(d["ranges"]["error_reduce_ms"]) == 2
-    assert d["one_stream"]["same_outputs_as_the_timed_region"] is True and d["roofline"]["launches_per_step"] == 2
+    assert d["one_stream"]["same_outputs_as_the_timed_region"] is True and d["roofline_overlapped"]["launches_per_step"] == 2
+    assert abs(d["roofline"]["avg_ms"] - max(d["one_stream"]["error_reduce_ms"], d["one_stream"]["poisson_call_ms"])) < 1e-9
     assert 0 < d["roofline_pass"]["frac"] < 1
     assert d["sustained"]["passes"] == 40 and d["cold_hbm"]["batches"] == 2

@@ -806,7 +806,44 @@ def test_baseline_configs_4_and_5_full_size(ctx, name, P, S, T, depth):
         assert torch.equal(getattr(fin, k).view(torch.uint8), getattr(fin24, k).view(torch.uint8)), k
     assert torch.equal(res["call_mask"], res24["call_mask"]) and c24.n_calls_total(res24) == n
     c24.close()
-    del nor, tum, res, fin, n24, t24, fin24, res24
+    del n24, t24, fin24, res24
+    if depth <= 2000:
+        # config 4 in the uint16 layout the products hold it in: the compact-state kernel at S = 1024 (256 rows per wave), whole, as
+        # four position ranges inside the library, and streamed in four chunks of 256 samples through the accumulator table -- every
+        # output identical to the int32 pass above (whose slice the oracle checked)
+        c16 = Context(0)
+        c16.set_record_layout("u16")
+        n16, fits_n = c16.pack16(nor)
+        t16, fits_t = c16.pack16(tum)
+        assert fits_n and fits_t
+        fin16 = c16.error_estimate(n16, P)
+        assert c16.last_reduce_kernel() == "error_reduce_u16_kernel"
+        res16 = c16.poisson_call(t16, P, fin16.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 22)
+        assert c16.flags() == 0 and int(fin16.flags.item()) == 0
+        for k in ("rate", "thr", "code", "germ_present"):
+            assert torch.equal(getattr(fin, k).view(torch.uint8), getattr(fin16, k).view(torch.uint8)), k
+        assert torch.equal(res["call_mask"], res16["call_mask"]) and c16.n_calls_total(res16) == n
+        c16.set_ranges(4)
+        finr = c16.error_estimate(n16, P)
+        resr = c16.poisson_call(t16, P, finr.thr, refc, 100, mode=POISSON_PREFILTER, capacity=1 << 22)
+        assert c16.flags() == 0  # joins
+        c16.set_ranges(1)
+        for k in ("rate", "thr", "code", "germ_present"):
+            assert torch.equal(getattr(fin, k).view(torch.uint8), getattr(finr, k).view(torch.uint8)), k
+        assert torch.equal(res["call_mask"], resr["call_mask"]) and c16.n_calls_total(resr) == n
+        acc = c16.new_acc(P)
+        v16 = n16.view(S, P, 8)
+        fins = None
+        for ci in range(4):
+            rec = c16.records(v16[ci * 256:(ci + 1) * 256], "u16", 256)
+            fins = c16.error_reduce_records(rec, P, acc, 0.002, 100, first_sample=ci * 256, accumulate=ci > 0, finalize=ci == 3, summary=True)
+            assert c16.last_reduce_kernel() == "error_reduce_u16_kernel"
+        assert c16.flags() == 0
+        for k in ("rate", "thr", "code", "germ_present"):
+            assert torch.equal(getattr(fin, k).view(torch.uint8), getattr(fins, k).view(torch.uint8)), k
+        c16.close()
+        del n16, t16, fin16, res16, finr, resr, acc, fins
+    del nor, tum, res, fin
     torch.cuda.empty_cache()
 
 
