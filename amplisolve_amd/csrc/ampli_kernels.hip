@@ -1858,6 +1858,138 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// poisson_call, all-scores mode (AMPLI_POISSON_FULL), round 5: every score of every record, as the reference evaluates them
+// (VC:895-896), scheduled by how much work a score is.  On a ctDNA-like panel (config 3) 45 % of the (record, alternative,
+// strand) scores have k = 0 (Q = 0, VC:3858-3861 + 3873-3876), 53 % take the continued fraction with k - 1 <= 3 steps
+// (z = RD err > k >= 1), 2.5 % take the series (16+ terms) and 0.7 % a continued fraction of up to 99 steps.  Evaluated lane by
+// lane (round 4's kernel, kept for the dense-VAF validation output) a wave pays the series AND the longest continued fraction
+// of its 64 lanes in every one of its six score slots: 80 % of the wave-slots hold a series lane, a third a lane with k > 20.
+// Here a lane scores its LIGHT items in place (k = 0, the special error codes, a continued fraction of at most PF_LIGHT_STEPS
+// steps: one log, one exp, one division, one log10) and hands the HEAVY ones -- series; longer continued fractions -- to two
+// lists in LDS, which the whole workgroup then evaluates densely, a list at a time: a wave runs ONE of the two loops, over
+// lanes that all need it.  The same scorer (ampli_poisson_score_dense), item for item: identical results.
+// ---------------------------------------------------------------------------
+constexpr int PF_LIGHT_STEPS = 3;
+constexpr int PF_LIST = 384; // heavy items per list and sample row of a workgroup (config 3: ~40 series + ~10 long fractions of 1536 scores)
+struct PfItem { int k, d; float err; int slot; }; // slot = owning thread * 6 + alternative * 2 + strand
+
+template <int LAY>
+__global__ __launch_bounds__(256, 4) void poisson_full_kernel(
+    const RecView rv, const long long P, const long long E, const unsigned *__restrict__ ext_pos,
+    const int T, const float *__restrict__ thr, const long long thr_L, const size_t thr_bb,
+    const unsigned char *__restrict__ ref_code, const int cov,
+    unsigned char *__restrict__ call_mask, ampli_call *__restrict__ calls, const long long capacity,
+    unsigned long long *__restrict__ n_calls, double *__restrict__ qd, const double *__restrict__ lgtab)
+{
+    constexpr int RB = rec_bytes_of<LAY>();
+    __shared__ PfItem items[2][PF_LIST]; // [0] series, [1] long continued fractions; a full list sends its item back to be scored in place
+    __shared__ double res[256 * 6];      // by owning thread and score slot (the three alternatives x two strands)
+    __shared__ int n_list[2];
+    const long long R = P + E;
+    const long long r_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = r_raw < R; // lanes past the end keep company at the barriers
+    const long long r = in_range ? r_raw : R - 1;
+    const long long p = r < P ? r : (long long)ext_pos[r - P];
+    float th[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        th[0][nt] = thr_at(thr, P, thr_L, thr_bb, 0 * 4 + nt, p); // VC:887-890
+        th[1][nt] = thr_at(thr, P, thr_L, thr_bb, 1 * 4 + nt, p);
+    }
+    const int ref = ref_code[p];
+    const int t0 = blockIdx.y * PC_SAMPLES;
+    for (int dt = 0; dt < PC_SAMPLES; ++dt) {
+        const int t = t0 + dt;
+        if (t >= T) break; // block-uniform
+        if (threadIdx.x < 2) n_list[threadIdx.x] = 0;
+        __syncthreads(); // also: every lane has collected its results of the previous sample
+        const size_t o = (size_t)t * R + r;
+        const char *q = r < P ? rv.base + ((size_t)t * (size_t)rv.row_stride + (size_t)r) * RB
+                              : rv.ext + ((size_t)t * (size_t)rv.ext_stride + (size_t)(r - P)) * RB;
+        int4 r0, r1;
+        rec_decode<LAY>(rec_load_at<LAY>(q), r0, r1);
+        const bool present = r0.x != AMPLI_ABSENT;
+        const int fw[4] = {r0.x, r0.y, r0.z, r0.w};
+        const int bw[4] = {r1.x, r1.y, r1.z, r1.w};
+        const int FW = fw[0] + fw[1] + fw[2] + fw[3]; // VC:760
+        const int BW = bw[0] + bw[1] + bw[2] + bw[3]; // VC:761
+        const int *rdp = r < P ? rv.rd : rv.rd_ext;   // the RD column of lines where it is not A+C+G+T (VC:762-765)
+        const int rdc = rdp ? rdp[r < P ? (size_t)t * P + r : (size_t)t * E + (r - P)] : AMPLI_ABSENT;
+        const int RD = rdc != AMPLI_ABSENT ? rdc : FW + BW;
+        const bool covok = FW >= cov && BW >= cov;    // VC:898
+        const bool scored = in_range && present && ref <= 3;
+        double qv[4][2];
+        unsigned pending = 0; // bit nt * 2 + strand: the score comes back through res[]
+        int alt = 0;          // running index of the alternative nucleotide (0 .. 2)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            qv[nt][0] = qv[nt][1] = -1.0;
+            if (!scored || nt == ref) continue;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const int k = st ? bw[nt] : fw[nt], d = st ? BW : RD - BW; // VC:895-896: forward depth is RD - RD_reverse
+                float err = th[st][nt];
+                if (err == -1) { qv[nt][st] = -888.0; continue; } // VC:3844-3849
+                if (err == 0) err = 0.0010008f;                    // VC:3852-3856
+                if (k == 0) { qv[nt][st] = 0.0; continue; }        // VC:3858-3861, VC:3873-3876
+                const double z = (double)d * err;                  // VC:3864
+                const bool series = z <= 1. || z < (double)k;      // VC:3728
+                // not a count, z <= 0 or NaN: the literal arithmetic, in place (never on real panels)
+                const bool odd = k < 0 || !(z > 0);
+                int at = PF_LIST;
+                if (!odd && (series || k - 1 > PF_LIGHT_STEPS)) at = atomicAdd(&n_list[series ? 0 : 1], 1);
+                if (at < PF_LIST) {
+                    PfItem it;
+                    it.k = k; it.d = d; it.err = err; it.slot = (int)threadIdx.x * 6 + alt * 2 + st;
+                    items[series ? 0 : 1][at] = it;
+                    pending |= 1u << (nt * 2 + st);
+                } else {
+                    qv[nt][st] = ampli_poisson_score_dense(k, d, err, lgtab, AMPLI_LGTAB);
+                }
+            }
+            ++alt;
+        }
+        __syncthreads();
+        // the heavy items, densely: all lanes of a pass run the same loop (series: 16+ terms; continued fraction: 4 .. 99 steps)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const int n = min(n_list[l], PF_LIST);
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const PfItem it = items[l][i];
+                res[it.slot] = ampli_poisson_score_dense(it.k, it.d, it.err, lgtab, AMPLI_LGTAB);
+            }
+        }
+        __syncthreads();
+        if (!in_range) continue;
+        unsigned mask = 0;
+        alt = 0;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                if ((pending >> (nt * 2 + st)) & 1) qv[nt][st] = res[threadIdx.x * 6 + alt * 2 + st];
+            if (scored && nt != ref) ++alt;
+            if (qd) { qd[o * 8 + nt * 2 + 0] = qv[nt][0]; qd[o * 8 + nt * 2 + 1] = qv[nt][1]; } // -1: not scored (reference nucleotide, absent record)
+            if (!scored || nt == ref) continue;
+            const double q_fw = qv[nt][0], q_bw = qv[nt][1];
+            const bool is_call = covok && q_fw >= 5 && q_bw >= 5; // VC:898
+            const double lo = 5.0 - AMPLI_CALL_GATE_EPS, hi = 5.0 + AMPLI_CALL_GATE_EPS;
+            const bool near_gate = covok && q_fw >= lo && q_bw >= lo && (q_fw < hi || q_bw < hi); // AMPLI_CALL_BORDERLINE
+            if (is_call) mask |= 1u << nt;
+            if ((is_call || near_gate) && n_calls) {
+                const long long idx = call_slot(n_calls, capacity);
+                if (calls && idx >= 0) {
+                    ampli_call c;
+                    call_fill(c, t, (int)r, nt, RD, q_fw, q_bw, fw[nt], bw[nt], FW, BW, near_gate ? AMPLI_CALL_BORDERLINE : 0);
+                    calls[idx] = c;
+                }
+            }
+        }
+        call_mask[o] = (unsigned char)mask;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // poisson_call, prefilter mode = two kernels.
 //
 // poisson_stream_kernel: one lane per record, one WAVE per (64-record tile, group of tumour rows); the four waves of a
@@ -2890,6 +3022,18 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
                        (long long)E, d_ext_pos, (int)T, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, d_call_mask, d_calls,       \
                        (long long)capacity,                                                                                     \
                        d_n_calls, d_q, d_af, (const double *)ctx->d_lgtab)
+    if (mode == AMPLI_POISSON_FULL && !d_af) { // all six scores of every record: light ones in place, heavy ones compacted per workgroup
+        { int rcl = ensure_lgtab(ctx); if (rcl) return rcl; }
+#define AMPLI_LAUNCH_PF(UV)                                                                                                           \
+    hipLaunchKernelGGL((poisson_full_kernel<UV>), grid, dim3(256), 0, main_stream(ctx), co.rv, (long long)P, (long long)E, d_ext_pos, \
+                       (int)T, d_thr, thr_L, thr_bb, d_ref_code, (int)cov, d_call_mask, d_calls, (long long)capacity, d_n_calls, d_q, \
+                       (const double *)ctx->d_lgtab)
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PF(AMPLI_RECORDS_U24);
+        else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_PF(AMPLI_RECORDS_U16);
+        else AMPLI_LAUNCH_PF(AMPLI_RECORDS_I32);
+#undef AMPLI_LAUNCH_PF
+        return check_launch(ctx, "poisson_full_kernel");
+    }
     if (mode == AMPLI_POISSON_FULL) {
         { int rcl = ensure_lgtab(ctx); if (rcl) return rcl; }
         if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_PC(AMPLI_POISSON_FULL, AMPLI_RECORDS_U24);

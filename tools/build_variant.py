@@ -46,6 +46,11 @@ V = {
     #  keeps two copies of the numerator and branches around the update; two named record sets instead of three -- 107 against 102 us)
     # (three / five sample chunks per workgroup -- 192 / 320 threads, a tree over up to five waves in two LDS slots -- were measured
     #  with a generic form of the kernel's epilogue: 122-125 us / 128-131 us against 108-113 us with four)
+    # all-scores kernel (round 5) at three waves per SIMD without spills instead of four with 68-88 bytes of scratch
+    "pf_lb3": [("__global__ __launch_bounds__(256, 4) void poisson_full_kernel(", "__global__ __launch_bounds__(256, 3) void poisson_full_kernel(")],
+    # ... with every continued fraction heavy (light = k == 0 and the special codes only) / with up to 8 steps light
+    "pf_light0": [("constexpr int PF_LIGHT_STEPS = 3;", "constexpr int PF_LIGHT_STEPS = -1;")],
+    "pf_light8": [("constexpr int PF_LIGHT_STEPS = 3;", "constexpr int PF_LIGHT_STEPS = 8;")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }
