@@ -1860,18 +1860,23 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 // ---------------------------------------------------------------------------
 // poisson_call, all-scores mode (AMPLI_POISSON_FULL), round 5: every score of every record, as the reference evaluates them
 // (VC:895-896), scheduled by how much work a score is.  On a ctDNA-like panel (config 3) 45 % of the (record, alternative,
-// strand) scores have k = 0 (Q = 0, VC:3858-3861 + 3873-3876), 53 % take the continued fraction with k - 1 <= 3 steps
-// (z = RD err > k >= 1), 2.5 % take the series (16+ terms) and 0.7 % a continued fraction of up to 99 steps.  Evaluated lane by
-// lane (round 4's kernel, kept for the dense-VAF validation output) a wave pays the series AND the longest continued fraction
-// of its 64 lanes in every one of its six score slots: 80 % of the wave-slots hold a series lane, a third a lane with k > 20.
-// Here a lane scores its LIGHT items in place (k = 0, the special error codes, a continued fraction of at most PF_LIGHT_STEPS
-// steps: one log, one exp, one division, one log10) and hands the HEAVY ones -- series; longer continued fractions -- to two
-// lists in LDS, which the whole workgroup then evaluates densely, a list at a time: a wave runs ONE of the two loops, over
-// lanes that all need it.  The same scorer (ampli_poisson_score_dense), item for item: identical results.
+// strand) scores have k = 0 (p = 1, VC:3858-3861), 53 % lie on the continued fraction's side (z = RD err > k >= 1) with
+// k <= 4 -- 0.7 % there have k > 16 -- and 2.5 % take the series (16+ terms).  Evaluated lane by lane (round 4's kernel, kept for
+// the dense-VAF validation output) a wave pays the series AND the longest continued fraction of its 64 lanes in every one of
+// its six score slots: 80 % of the wave-slots hold a series lane, a third a lane with k > 20.
+// Here a lane evaluates its LIGHT scores in place -- k = 0, the special error codes, and the continued fraction's side up to
+// k = AMPLI_HORNER_K in its closed form (ampli_gammaq_horner_int: one exp, k - 1 FMAs) -- and hands the HEAVY ones -- series;
+// longer continued fractions -- to two lists in LDS, which the whole workgroup then evaluates densely, a list at a time: a wave
+// runs ONE of the two loops, over lanes that all need it.  The scorer is ampli_poisson_p_dense, item for item, wherever it runs.
+// p is kept, not Q: -10 log10 p is only taken where somebody reads it -- the dense output, and pairs that can pass the gate
+// (p <= PF_GATE_P on both strands, a superset of Q >= 5 - 1e-6; the decisions themselves are then made on Q, as ever).
 // ---------------------------------------------------------------------------
-constexpr int PF_LIGHT_STEPS = 3;
 constexpr int PF_LIST = 384; // heavy items per list and sample row of a workgroup (config 3: ~40 series + ~10 long fractions of 1536 scores)
+constexpr double PF_GATE_P = 0.3162279; // > 10^-(5 - 1e-6)/10 = 0.31622783...: Q >= 5 - AMPLI_CALL_GATE_EPS implies p <= PF_GATE_P
+constexpr double PF_P_CODE = 2.0, PF_P_NONE = 3.0; // in place of a p: err == -1 (Q = -888, VC:3844-3849) | not scored
 struct PfItem { int k, d; float err; int slot; }; // slot = owning thread * 6 + alternative * 2 + strand
+
+__device__ __forceinline__ double pf_q(const double p) { return p == PF_P_CODE ? -888.0 : p == PF_P_NONE ? -1.0 : ampli_q_from_p(p); }
 
 template <int LAY>
 __global__ __launch_bounds__(256, 4) void poisson_full_kernel(
@@ -1918,45 +1923,46 @@ __global__ __launch_bounds__(256, 4) void poisson_full_kernel(
         const int RD = rdc != AMPLI_ABSENT ? rdc : FW + BW;
         const bool covok = FW >= cov && BW >= cov;    // VC:898
         const bool scored = in_range && present && ref <= 3;
-        double qv[4][2];
-        unsigned pending = 0; // bit nt * 2 + strand: the score comes back through res[]
+        double pv[4][2];
+        unsigned pending = 0; // bit nt * 2 + strand: the p comes back through res[]
         int alt = 0;          // running index of the alternative nucleotide (0 .. 2)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            qv[nt][0] = qv[nt][1] = -1.0;
+            pv[nt][0] = pv[nt][1] = PF_P_NONE;
             if (!scored || nt == ref) continue;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const int k = st ? bw[nt] : fw[nt], d = st ? BW : RD - BW; // VC:895-896: forward depth is RD - RD_reverse
                 float err = th[st][nt];
-                if (err == -1) { qv[nt][st] = -888.0; continue; } // VC:3844-3849
-                if (err == 0) err = 0.0010008f;                    // VC:3852-3856
-                if (k == 0) { qv[nt][st] = 0.0; continue; }        // VC:3858-3861, VC:3873-3876
-                const double z = (double)d * err;                  // VC:3864
-                const bool series = z <= 1. || z < (double)k;      // VC:3728
-                // not a count, z <= 0 or NaN: the literal arithmetic, in place (never on real panels)
-                const bool odd = k < 0 || !(z > 0);
+                if (err == -1) { pv[nt][st] = PF_P_CODE; continue; } // VC:3844-3849
+                if (err == 0) err = 0.0010008f;                       // VC:3852-3856
+                if (k == 0) { pv[nt][st] = 1.0; continue; }           // VC:3858-3861
+                const double z = (double)d * err;                     // VC:3864
+                const bool series = z <= 1. || z < (double)k;         // VC:3728
+                // light: the closed form of the fraction's side; and, in place because it never happens on real panels, whatever
+                // is not a count or has z <= 0 / NaN (the literal arithmetic)
+                const bool light = k < 0 || !(z > 0) || (!series && k <= AMPLI_HORNER_K && z < 838860.8);
                 int at = PF_LIST;
-                if (!odd && (series || k - 1 > PF_LIGHT_STEPS)) at = atomicAdd(&n_list[series ? 0 : 1], 1);
+                if (!light) at = atomicAdd(&n_list[series ? 0 : 1], 1);
                 if (at < PF_LIST) {
                     PfItem it;
                     it.k = k; it.d = d; it.err = err; it.slot = (int)threadIdx.x * 6 + alt * 2 + st;
                     items[series ? 0 : 1][at] = it;
                     pending |= 1u << (nt * 2 + st);
                 } else {
-                    qv[nt][st] = ampli_poisson_score_dense(k, d, err, lgtab, AMPLI_LGTAB);
+                    pv[nt][st] = ampli_poisson_p_dense(k, d, err, lgtab, AMPLI_LGTAB);
                 }
             }
             ++alt;
         }
         __syncthreads();
-        // the heavy items, densely: all lanes of a pass run the same loop (series: 16+ terms; continued fraction: 4 .. 99 steps)
+        // the heavy items, densely: all lanes of a pass run the same loop (series: 16+ terms; continued fraction: 16 .. 99 steps)
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
             const int n = min(n_list[l], PF_LIST);
             for (int i = threadIdx.x; i < n; i += 256) {
                 const PfItem it = items[l][i];
-                res[it.slot] = ampli_poisson_score_dense(it.k, it.d, it.err, lgtab, AMPLI_LGTAB);
+                res[it.slot] = ampli_poisson_p_dense(it.k, it.d, it.err, lgtab, AMPLI_LGTAB);
             }
         }
         __syncthreads();
@@ -1967,14 +1973,15 @@ __global__ __launch_bounds__(256, 4) void poisson_full_kernel(
         for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                if ((pending >> (nt * 2 + st)) & 1) qv[nt][st] = res[threadIdx.x * 6 + alt * 2 + st];
+                if ((pending >> (nt * 2 + st)) & 1) pv[nt][st] = res[threadIdx.x * 6 + alt * 2 + st];
             if (scored && nt != ref) ++alt;
-            if (qd) { qd[o * 8 + nt * 2 + 0] = qv[nt][0]; qd[o * 8 + nt * 2 + 1] = qv[nt][1]; } // -1: not scored (reference nucleotide, absent record)
-            if (!scored || nt == ref) continue;
-            const double q_fw = qv[nt][0], q_bw = qv[nt][1];
-            const bool is_call = covok && q_fw >= 5 && q_bw >= 5; // VC:898
+            if (qd) { qd[o * 8 + nt * 2 + 0] = pf_q(pv[nt][0]); qd[o * 8 + nt * 2 + 1] = pf_q(pv[nt][1]); } // -1: not scored (reference nucleotide, absent record)
+            // VC:898 needs Q >= 5 on both strands: nothing with p > PF_GATE_P on a strand can pass it or lie within 1e-6 of it
+            if (!(covok && pv[nt][0] <= PF_GATE_P && pv[nt][1] <= PF_GATE_P)) continue;
+            const double q_fw = ampli_q_from_p(pv[nt][0]), q_bw = ampli_q_from_p(pv[nt][1]);
+            const bool is_call = q_fw >= 5 && q_bw >= 5; // VC:898 (coverage checked above)
             const double lo = 5.0 - AMPLI_CALL_GATE_EPS, hi = 5.0 + AMPLI_CALL_GATE_EPS;
-            const bool near_gate = covok && q_fw >= lo && q_bw >= lo && (q_fw < hi || q_bw < hi); // AMPLI_CALL_BORDERLINE
+            const bool near_gate = q_fw >= lo && q_bw >= lo && (q_fw < hi || q_bw < hi); // AMPLI_CALL_BORDERLINE
             if (is_call) mask |= 1u << nt;
             if ((is_call || near_gate) && n_calls) {
                 const long long idx = call_slot(n_calls, capacity);

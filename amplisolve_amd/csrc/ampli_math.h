@@ -273,23 +273,44 @@ AMPLI_FN double ampli_gammaq_cf_int(int k, double z, double prefactor /* exp(s l
     return prefactor * B1 / A1; // exp(...) / f, f = A_j / B_j  (VC:3751)
 }
 
+// Q(k, z) for an integer k in 1 .. AMPLI_HORNER_K on the continued fraction's side (z > k), round 5.  For an integer s the
+// fraction of VC:3733-3752 ends at j = s (a_s = 0: the step is the identity) and its value there is a rational function,
+//   f = z^k / H_k(z),   H_k(z) = sum_{i<k} z^i (k-1)! / i!   (H_1 = 1, H_{j+1} = j H_j + z^j),
+// so exp(s log z - z - lgamma(s)) / f  =  exp(-z - lgamma(k)) H_k(z): the Poisson sum e^-z sum_{i<k} z^i / i! with the
+// reference's own lgamma (the table of its Lanczos values).  One exp and k - 1 FMAs -- no log z, no division, no convergence
+// test; the reference's early exit (|C_j D_j - 1| < 1e-14) leaves out steps that change f by < 1e-14 each.  Within 1e-13
+// relative of the literal scorer (tests/test_math_host.py).  H_16 < 16! z^15 < 1e103 for every z < 2^24 x 0.05: no scaling.
+#define AMPLI_HORNER_K 16
+AMPLI_FN double ampli_gammaq_horner_int(int k, double z, double lgk /* lgamma(k) */)
+{
+    double H = 1., zp = 1.;
+    for (int j = 1; j < k; ++j) {
+        zp *= z;
+        H = fma((double)j, H, zp);
+    }
+    return exp(-z - lgk) * H;
+}
+
+// p of a count k > 0 against an effective error (neither -1 nor 0): VC:3864-3865 through the forms above
+AMPLI_FN double ampli_poisson_p_dense(int32_t k, int32_t rd, float err, const double *lgtab, int ntab)
+{
+    if (k < 0) return 1 - ampli_kf_gammaq((double)k, (double)rd * err); // not a count: the literal path
+    const double s = (double)k, z = (double)rd * err; // VC:3864: double * float
+    if (z <= 1. || z < s) { // VC:3728
+        if (!(z > 0)) return 1 - ampli_kf_gammaq(s, z); // z <= 0 or NaN: whatever the literal arithmetic gives
+        const double P = ampli_gammap_series_int(s, z, exp(s * log(z) - z - ampli_lgamma_int(k + 1, lgtab, ntab)));
+        return 1 - (1. - P); // VC:3865 on top of VC:3728
+    }
+    if (k <= AMPLI_HORNER_K && z < 838860.8) return 1 - ampli_gammaq_horner_int(k, z, ampli_lgamma_int(k, lgtab, ntab));
+    return 1 - ampli_gammaq_cf_int(k, z, exp(s * log(z) - z - ampli_lgamma_int(k, lgtab, ntab)));
+}
+
 AMPLI_FN double ampli_poisson_score_dense(int32_t k, int32_t rd, float err, const double *lgtab, int ntab)
 {
     if (err == -1) return -888.0;   // VC:3844-3849
     if (err == 0) err = 0.0010008f; // VC:3852-3856
     if (k == 0) return 0.0;         // VC:3858-3861: p = 1 -> Q = 0 (VC:3873-3876)
-    if (k < 0) return ampli_q_from_p(1 - ampli_kf_gammaq((double)k, (double)rd * err)); // not a count: the literal path
-    const double s = (double)k, z = (double)rd * err; // VC:3864: double * float
-    const double lz = log(z);
-    double p;
-    if (z <= 1. || z < s) { // VC:3728
-        if (!(z > 0)) return ampli_q_from_p(1 - ampli_kf_gammaq(s, z)); // z <= 0 or NaN: whatever the literal arithmetic gives
-        const double P = ampli_gammap_series_int(s, z, exp(s * lz - z - ampli_lgamma_int(k + 1, lgtab, ntab)));
-        p = 1 - (1. - P); // VC:3865 on top of VC:3728
-    } else {
-        p = 1 - ampli_gammaq_cf_int(k, z, exp(s * lz - z - ampli_lgamma_int(k, lgtab, ntab)));
-    }
-    return ampli_q_from_p(p);
+    return ampli_q_from_p(ampli_poisson_p_dense(k, rd, err, lgtab, ntab));
 }
 
 // Exact-decision bound used by AMPLI_POISSON_PREFILTER: when k <= m the

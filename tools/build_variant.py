@@ -48,9 +48,10 @@ V = {
     #  with a generic form of the kernel's epilogue: 122-125 us / 128-131 us against 108-113 us with four)
     # all-scores kernel (round 5) at three waves per SIMD without spills instead of four with 68-88 bytes of scratch
     "pf_lb3": [("__global__ __launch_bounds__(256, 4) void poisson_full_kernel(", "__global__ __launch_bounds__(256, 3) void poisson_full_kernel(")],
-    # ... with every continued fraction heavy (light = k == 0 and the special codes only) / with up to 8 steps light
-    "pf_light0": [("constexpr int PF_LIGHT_STEPS = 3;", "constexpr int PF_LIGHT_STEPS = -1;")],
-    "pf_light8": [("constexpr int PF_LIGHT_STEPS = 3;", "constexpr int PF_LIGHT_STEPS = 8;")],
+    # (round 5, first form of that kernel -- up to 3 continued-fraction steps in place through the generic loop: 1.03-1.11 ms; every
+    #  fraction through the dense list: 1.10-1.17; up to 8 steps in place: 1.16-1.24; three waves per SIMD without spills: 1.16-1.24)
+    # ... with the closed form only up to k = 4 / k = 8
+    "pf_h4": [("#define AMPLI_HORNER_K 16", "#define AMPLI_HORNER_K 4")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }
@@ -58,7 +59,14 @@ V = {
 
 def build(name):
     text = open(SRC).read()
+    math_h = os.path.join(ROOT, "amplisolve_amd", "csrc", "ampli_math.h")
+    math_text = open(math_h).read()
     for old, new in V[name]:
+        if old in math_text and old not in text:  # a substitution in the math header: the variant includes its own copy
+            alt_h = os.path.join(ROOT, "amplisolve_amd", "csrc", f"_variant_{name}_math.h")
+            open(alt_h, "w").write(math_text.replace(old, new))
+            text = text.replace('#include "ampli_math.h"', f'#include "_variant_{name}_math.h"')
+            continue
         assert old in text, (name, old)
         text = text.replace(old, new)
     os.makedirs(OUT, exist_ok=True)
@@ -70,6 +78,9 @@ def build(name):
                         os.path.join(OUT, f"{name}.so"), src, *others], check=True)
     finally:
         os.remove(src)
+        alt_h = os.path.join(ROOT, "amplisolve_amd", "csrc", f"_variant_{name}_math.h")
+        if os.path.exists(alt_h):
+            os.remove(alt_h)
 
 
 if __name__ == "__main__":
