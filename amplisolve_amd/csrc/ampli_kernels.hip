@@ -1860,14 +1860,15 @@ __global__ __launch_bounds__(256) void poisson_call_kernel(
 // ---------------------------------------------------------------------------
 // poisson_call, all-scores mode (AMPLI_POISSON_FULL), round 5: every score of every record, as the reference evaluates them
 // (VC:895-896), scheduled by how much work a score is.  On a ctDNA-like panel (config 3) 45 % of the (record, alternative,
-// strand) scores have k = 0 (p = 1, VC:3858-3861), 53 % lie on the continued fraction's side (z = RD err > k >= 1) with
-// k <= 4 -- 0.7 % there have k > 16 -- and 2.5 % take the series (16+ terms).  Evaluated lane by lane (round 4's kernel, kept for
-// the dense-VAF validation output) a wave pays the series AND the longest continued fraction of its 64 lanes in every one of
-// its six score slots: 80 % of the wave-slots hold a series lane, a third a lane with k > 20.
+// strand) scores have k = 0 (p = 1, VC:3858-3861), 53 % lie on the continued fraction's side (z = RD err > k >= 1), nearly all
+// of them with k <= 4 (0.7 % with k > 20), and 2.5 % take the series (16+ terms).  Evaluated lane by lane (round 4's kernel,
+// kept for the dense-VAF validation output) a wave pays the series AND the longest continued fraction of its 64 lanes in every
+// one of its six score slots: 80 % of the wave-slots hold a series lane, a third a lane with k > 20.
 // Here a lane evaluates its LIGHT scores in place -- k = 0, the special error codes, and the continued fraction's side up to
 // k = AMPLI_HORNER_K in its closed form (ampli_gammaq_horner_int: one exp, k - 1 FMAs) -- and hands the HEAVY ones -- series;
 // longer continued fractions -- to two lists in LDS, which the whole workgroup then evaluates densely, a list at a time: a wave
 // runs ONE of the two loops, over lanes that all need it.  The scorer is ampli_poisson_p_dense, item for item, wherever it runs.
+// Config 3, uint16 records: 1.49 ms (round 4) -> 1.03-1.11 (lists; generic fraction loop in place) -> 0.55 ms (closed form).
 // p is kept, not Q: -10 log10 p is only taken where somebody reads it -- the dense output, and pairs that can pass the gate
 // (p <= PF_GATE_P on both strands, a superset of Q >= 5 - 1e-6; the decisions themselves are then made on Q, as ever).
 // ---------------------------------------------------------------------------
@@ -1956,7 +1957,7 @@ __global__ __launch_bounds__(256, 4) void poisson_full_kernel(
             ++alt;
         }
         __syncthreads();
-        // the heavy items, densely: all lanes of a pass run the same loop (series: 16+ terms; continued fraction: 16 .. 99 steps)
+        // the heavy items, densely: all lanes of a pass run the same loop (series: 16+ terms; continued fraction: 4 .. 99 steps)
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
             const int n = min(n_list[l], PF_LIST);

@@ -279,8 +279,10 @@ AMPLI_FN double ampli_gammaq_cf_int(int k, double z, double prefactor /* exp(s l
 // so exp(s log z - z - lgamma(s)) / f  =  exp(-z - lgamma(k)) H_k(z): the Poisson sum e^-z sum_{i<k} z^i / i! with the
 // reference's own lgamma (the table of its Lanczos values).  One exp and k - 1 FMAs -- no log z, no division, no convergence
 // test; the reference's early exit (|C_j D_j - 1| < 1e-14) leaves out steps that change f by < 1e-14 each.  Within 1e-13
-// relative of the literal scorer (tests/test_math_host.py).  H_16 < 16! z^15 < 1e103 for every z < 2^24 x 0.05: no scaling.
-#define AMPLI_HORNER_K 16
+// relative of the literal scorer (tests/test_math_host.py).  K = 4 covers 96 % of the scores on that side of a ctDNA-like panel
+// (config 3: all-scores mode 0.55 ms; K = 16: 0.58 ms -- a wave runs the longest loop of its lanes; H_16 would still be far
+// from overflow for z < 2^24 x 0.05, the bound kept below).
+#define AMPLI_HORNER_K 4
 AMPLI_FN double ampli_gammaq_horner_int(int k, double z, double lgk /* lgamma(k) */)
 {
     double H = 1., zp = 1.;

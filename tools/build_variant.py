@@ -50,8 +50,9 @@ V = {
     "pf_lb3": [("__global__ __launch_bounds__(256, 4) void poisson_full_kernel(", "__global__ __launch_bounds__(256, 3) void poisson_full_kernel(")],
     # (round 5, first form of that kernel -- up to 3 continued-fraction steps in place through the generic loop: 1.03-1.11 ms; every
     #  fraction through the dense list: 1.10-1.17; up to 8 steps in place: 1.16-1.24; three waves per SIMD without spills: 1.16-1.24)
-    # ... with the closed form only up to k = 4 / k = 8
-    "pf_h4": [("#define AMPLI_HORNER_K 16", "#define AMPLI_HORNER_K 4")],
+    # ... with the closed form up to k = 16 / k = 8 instead of 4
+    "pf_h16": [("#define AMPLI_HORNER_K 4", "#define AMPLI_HORNER_K 16")],
+    "pf_h8": [("#define AMPLI_HORNER_K 4", "#define AMPLI_HORNER_K 8")],
     # poisson_stream without queue pushes
     "nopush": [("        if (__any(pushmask != 0)) { // rare", "        if (__any(pushmask != 0) && P < 0) { // variant: never")],
 }
