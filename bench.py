@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--whole-rounds", type=int, default=4, help="N = 1: after the timed region, time the dominant reduce kernel on a panel of this many "
                     "whole rounds of resident workgroups (what the partly filled last round of the configuration costs); 0 = skip")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="time the reference's error estimation on ALL normals of config 3 (~6 min on one core)")
+    ap.add_argument("--e2e", default=None, choices=list(CONFIGS), help="ONLY the end-to-end leg of that configuration, nothing else: its files written as ASEQ text, "
+                    "both executables with their phase clocks, the reference's error estimation on a 6-file sample.  Opt-in because of its size "
+                    "(c4: 2048 files, ~13 GB of text); prints one JSON object {\"e2e\": {...}}")
     ap.add_argument("--mode", default="prefilter", choices=["prefilter", "full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--splits", type=int, default=0, help="error_reduce sample splits (0 = auto)")
@@ -307,6 +310,17 @@ def cpu_baseline(cfg, thr, ref_code, full=False):
         H.ampli_host_synth_write_aseq(os.path.join(d, "N").encode(), b"N", P, n_ref, 0, SEED, depth, 0, 0)
         open(os.path.join(d, "dups.txt"), "w").close()
         r = reference_ee_run(d, "N", "ref")
+        vc_load = None
+        if r and os.path.exists(getattr(orc, "REF_VC_DRIVER", "")):
+            # the calling half's table load, by the reference's own storeInputFile (VC:430-576, compiled in place without Boost) on the
+            # table the reference just wrote for this panel: P rows, four threshold and four germ-max cells each
+            try:
+                rc_, _, tm_, _, _, _ = _run_timed([orc.REF_VC_DRIVER, "time", os.path.relpath(r["table"], d), "dummy.vcf"], d)
+                if rc_ == 0 and "storeInputFile" in tm_:
+                    vc_load = dict(seconds=tm_["storeInputFile"], positions=int(tm_.get("storeInputFile.positions", 0)), cores=1,
+                                   what="reference storeInputFile (VC:430-576) on the workload's error table, once per AmpliSolveVariantCalling run")
+            except Exception:  # noqa: BLE001
+                vc_load = None
         if r:
             ee = dict(records=r["records"], seconds=r["seconds"], records_per_s=r["records_per_s"], cores=1, phases_s=r["phases"],
                       sample=f"{n_ref} of the {S} normal files of the workload ({P} positions each), reference AmpliSolveErrorEstimation.cpp -O2, "
@@ -341,13 +355,16 @@ def cpu_baseline(cfg, thr, ref_code, full=False):
     out["port"] = port
     out["ee"] = ee
     out["vc_scorer"] = vc
+    out["vc_table_load"] = vc_load
     if ee and vc:
         # one figure in the metric's unit: the workload's record mix through the reference's own code on one core
-        t_mix = P * S / ee["records_per_s"] + P * T / vc["tumour_records_per_s_1_core"]
+        t_load = vc_load["seconds"] if vc_load else 0.0
+        t_mix = P * S / ee["records_per_s"] + P * T / vc["tumour_records_per_s_1_core"] + t_load
         out.update(value=(P * S + P * T) / t_mix, cores=1, kind="reference",
                    sample=f"reference code on one host core, bounded sample of the same workload: error estimation {ee['records']} records in "
-                          f"{ee['seconds']:.1f} s; Poisson scorer {vc['evaluations']} evaluations in {vc['seconds_1_core']:.1f} s (scorer only); value = "
-                          "(normal + tumour records of the workload) / (their time at those two rates)")
+                          f"{ee['seconds']:.1f} s; calling = Poisson scorer {vc['evaluations']} evaluations in {vc['seconds_1_core']:.1f} s + the table load "
+                          f"(storeInputFile, {t_load:.2f} s once) -- callVariants itself (parsing, hash look-ups) needs Boost and is not in it; value = "
+                          "(normal + tumour records of the workload) / (their time at those rates)")
     else:
         out.update(value=port["value"], cores=1, kind="port", sample=port["sample"])
     return out
@@ -397,6 +414,18 @@ def self_launch(args):
 
 def main():
     args = parse_args()
+    if args.e2e:
+        cfg = CONFIGS[args.e2e]
+        t0 = time.perf_counter()
+        leg = e2e_leg(args.e2e, cfg, ref_files=6)
+        leg["leg_wall_s"] = time.perf_counter() - t0
+        ee, vc = leg.get("error_estimation", {}), leg.get("variant_calling", {})
+        if ee and vc:  # what bounds a cohort of this size: the largest critical phase of each command line
+            for side in (ee, vc):
+                crit = {k: v for k, v in (side.get("breakdown_s") or {}).items() if not k.endswith("*") and k not in ("wall_in_main", "unattributed")}
+                side["largest_critical_phases"] = sorted(crit.items(), key=lambda kv: -kv[1])[:4]
+        print(json.dumps({"e2e": {args.e2e: leg}}))
+        return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)  # no GPU call has been made in this process
     # ONE JSON line on stdout and nothing else: RCCL prints a version banner to stdout when its first communicator comes up,

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 REF_EE_DRIVER = os.path.join(HERE, "_ref", "ee_ref_driver")
 REF_VC_SCORER = os.path.join(HERE, "_ref", "libvc_scorer_ref.so")
+REF_VC_DRIVER = os.path.join(HERE, "_ref", "vc_ref_driver")
 
 _lib = None
 

@@ -19,10 +19,13 @@
 //   storeInputFile, then for every data row of the table in file order (first row of a position only; key as VC:828):
 //     C <chrom> <position> <find_kmer_down> <find_kmer_up> <homopolymerTest for sub = A> <C> <G> <T>
 //   with the arguments callVariants passes (VC:964-965, 1017: ReferenceBase_Hash, chrom, the integer position).
+// usage: vc_ref_driver time <error_table> <dummy_vcf_out>
+//   storeInputFile alone, timed: "TIMING storeInputFile <seconds> positions <n> thresholds <n>"
 // usage: vc_ref_driver order <tumour_dir> <list_file_out>
 //   generateCountList + storeCountList as main() calls them (VC:328-333), then the iteration order of
 //   TumourFileList_Hash -- the order callVariants visits the files in (VC:672) -- as "<sample name>\t<listed path>".
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,7 +59,7 @@ static void dump_sorted(const char *tag, const std::unordered_map<std::string, s
 int main(int argc, char **argv)
 {
     if (argc != 4) {
-        fprintf(stderr, "usage: vc_ref_driver maps|context <error_table> <dummy_vcf_out> | order <tumour_dir> <list_file_out>\n");
+        fprintf(stderr, "usage: vc_ref_driver maps|context|time <error_table> <dummy_vcf_out> | order <tumour_dir> <list_file_out>\n");
         return 2;
     }
     const std::string mode = argv[1];
@@ -91,6 +94,14 @@ int main(int argc, char **argv)
             for (const char sub : {'A', 'C', 'G', 'T'}) std::cout << " " << homopolymerTest(down, up, sub);
             std::cout << "\n";
         }
+        return 0;
+    }
+    if (mode == "time") { // wall time of the reference's own table load (VC:430-576), for bench.py's cpu_baseline
+        const auto t0 = std::chrono::steady_clock::now();
+        storeInputFile(argv[2], argv[3]);
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cout.rdbuf(ours);
+        std::cout << "TIMING storeInputFile " << s << " positions " << ReferenceBase_Hash.size() << " thresholds " << Thresholds_Hash_Analytic.size() << "\n";
         return 0;
     }
     if (mode == "order") {
