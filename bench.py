@@ -1141,7 +1141,7 @@ def main():
         # this same command (tools/collect_profiles.sh) and corrected as MI355X_MICROARCH.md prescribes; committed
         # under profiles/.  null when the workload is not the profiled one.
         traffic, traffic_src = None, None
-        pj = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("r04", "r03", "r02")) if os.path.exists(p)), "")
+        pj = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(p)), "")
         if args.config == "c3" and not multi and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
@@ -1215,10 +1215,10 @@ def main():
         # flops: lanes that are masked off in the divergent series / continued-fraction loops are counted too), so
         # issue_slot_frac -- FP64 wave instructions x 4 cycles / (SIMDs x clock x time) -- is the figure to read.
         try:
-            fk = next((v for k, v in pm["kernels"].items() if "poisson_call_kernel<0" in k and f", {lay}>" in k and "fp64_wave_instructions" in v), None) if traffic_src else None
+            fk = next((v for k, v in pm["kernels"].items() if f"poisson_full_kernel<{lay}>" in k and "fp64_wave_instructions" in v), None) if traffic_src else None
         except Exception:  # noqa: BLE001
             fk = None
-        out["roofline_fp64"] = {"bound": "fp64 vector issue", "kernel": f"poisson_call_kernel<0, {lay}> (all six scores of every record)", "avg_ms": t_call_full,
+        out["roofline_fp64"] = {"bound": "fp64 vector issue", "kernel": f"poisson_full_kernel<{lay}> (all six scores of every record)", "avg_ms": t_call_full,
                                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "achieved": (fk["fp64_flops_if_all_lanes_active"] / (t_call_full * 1e-3) / 1e12) if fk else None,
                                 "frac": (fk["fp64_flops_if_all_lanes_active"] / (t_call_full * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if fk else None,

@@ -2,7 +2,7 @@
 """Turn gpurun_out/prof_final/ (tools/collect_profiles.sh) into the committed summaries under profiles/<round>/."""
 import collections, csv, glob, json, os, shutil, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
@@ -14,6 +14,8 @@ def newest(pattern):
 
 for f in newest(f"{src}/trace/*/*kernel_stats.csv"):
     shutil.copy(f, f"{dst}/bench_c3_kernel_stats.csv")
+for f in newest(f"{src}/trace_ranges/*/*kernel_stats.csv"):  # the default command: position ranges on two streams
+    shutil.copy(f, f"{dst}/bench_c3_kernel_stats_ranges.csv")
 pm = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_f64"):
     for f in newest(f"{src}/{d}/*/*counter_collection.csv"):
@@ -44,7 +46,7 @@ for f in ("ampli_kernels.hip", "ampli_math.h"):
 # bench.py only quotes these counters while the kernel source is the one they were collected on
 json.dump({"kernel_source_sha256": h.hexdigest(), "command": "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0 --whole-rounds 0 --no-split-ranges",
            "kernels": out}, open(f"{dst}/pmc_summary.json", "w"), indent=1, sort_keys=True)
-for name in ("bench_default.log", "bench_under_trace.log"):
+for name in ("bench_default.log", "bench_under_trace.log", "bench_under_trace_ranges.log"):
     p = f"{src}/{name}"
     if os.path.exists(p):
         lines = [l for l in open(p) if l.startswith("{")]
