@@ -20,7 +20,7 @@
 //     C <chrom> <position> <find_kmer_down> <find_kmer_up> <homopolymerTest for sub = A> <C> <G> <T>
 //   with the arguments callVariants passes (VC:964-965, 1017: ReferenceBase_Hash, chrom, the integer position).
 // usage: vc_ref_driver time <error_table> <dummy_vcf_out>
-//   storeInputFile alone, timed: "TIMING storeInputFile <seconds> positions <n> thresholds <n>"
+//   storeInputFile alone, timed; on stderr: "TIMING storeInputFile <seconds> positions <n> thresholds <n>"
 // usage: vc_ref_driver order <tumour_dir> <list_file_out>
 //   generateCountList + storeCountList as main() calls them (VC:328-333), then the iteration order of
 //   TumourFileList_Hash -- the order callVariants visits the files in (VC:672) -- as "<sample name>\t<listed path>".
@@ -101,7 +101,8 @@ int main(int argc, char **argv)
         storeInputFile(argv[2], argv[3]);
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::cout.rdbuf(ours);
-        std::cout << "TIMING storeInputFile " << s << " positions " << ReferenceBase_Hash.size() << " thresholds " << Thresholds_Hash_Analytic.size() << "\n";
+        // on stderr, where bench.py reads every TIMING line of a child from
+        fprintf(stderr, "TIMING storeInputFile %.6f positions %zu thresholds %zu\n", s, ReferenceBase_Hash.size(), Thresholds_Hash_Analytic.size());
         return 0;
     }
     if (mode == "order") {

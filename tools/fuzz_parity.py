@@ -107,8 +107,9 @@ def main():
             general = bool(rng.random() < 0.3)
             groups = int(rng.choice([0, 1, 2, 4]))
             splits = int(rng.choice([0, 0, 1, 2, 3]))
-            if u16 and E == 0 and rng.random() < 0.5:
-                general, groups, splits = False, 1, 1  # the shape error_reduce_u16_kernel takes (the fused estimate below)
+            if u16 and rng.random() < 0.5:
+                general, groups, splits = False, 1, 1  # the shape error_reduce_u16_kernel takes (the fused estimate below); with E > 0 its tiles
+                                                       # of positions listed more than once go to the general kernel over the tile list
             ctx.set_tuning(splits, general=general, groups=groups)
             acc = ctx.error_reduce(dev, P, C_value, cov, E=E, dup_off=d_dup)
             fin2 = ctx.error_finalize(acc, C_value, cov)
@@ -129,6 +130,54 @@ def main():
             check_final(fin2, o_fin, "two-step finalize")
             check_final(fin1, o_fin, "fused estimate")
             n["reduce"] += 1
+            # ---- round 5: the cohort streamed in chunks through a table taken as streaming state (what the command lines launch); the
+            # compact kernel where its shape applies, one chunk now and then through the general kernel; the last chunk finalises, or
+            # (a shard) goes slice-major, in which case the buffers must be error_reduce_sliced's over the whole cohort ----
+            if S >= 2 and rng.random() < 0.6:
+                ncut = int(rng.integers(1, min(S, 4) + 1))
+                cuts = [0] + sorted(rng.choice(np.arange(1, S), size=ncut - 1, replace=False).tolist()) + [S] if ncut > 1 else [0, S]
+                sliced_last = rng.random() < 0.4
+                nsl = int(rng.integers(1, 5))
+                tacc = ctx.new_acc(P) if len(cuts) > 2 else None
+                ctx.set_tuning(1, groups=1)
+                Ls, _, _, _ = slice_geometry(P, nsl)
+                ws, wg = (torch.zeros(nsl * 21 * Ls, dtype=torch.float64, device="cuda"), torch.zeros(nsl * 8 * Ls, dtype=torch.float32, device="cuda"))
+                gs, gg = torch.zeros_like(ws), torch.zeros_like(wg)
+                finc = None
+                R = P + E
+                view = dev.view(S, R, -1)
+                for ci in range(len(cuts) - 1):
+                    a, b = cuts[ci], cuts[ci + 1]
+                    rec = ctx.records(view[a:b].contiguous(), layout, b - a, E=E, dup_off=d_dup)
+                    ctx.set_reduce_compact(bool(rng.random() < 0.8))
+                    last = ci == len(cuts) - 2
+                    if last and sliced_last:
+                        ctx.error_reduce_records_sliced(rec, P, tacc, nsl, gs, gg, C_value, cov, first_sample=a, accumulate=ci > 0)
+                    else:
+                        finc = ctx.error_reduce_records(rec, P, tacc, C_value, cov, first_sample=a, accumulate=ci > 0, finalize=last, summary=True)
+                ctx.set_reduce_compact(True)
+                if sliced_last:
+                    ctx.set_reduce_compact(False)
+                    ctx.error_reduce_sliced(dev, P, nsl, ws, wg, C_value, cov, E=E, dup_off=d_dup)
+                    ctx.set_reduce_compact(True)
+                    if not (torch.equal(gs.view(torch.int64), ws.view(torch.int64)) and torch.equal(gg.view(torch.int32), wg.view(torch.int32))):
+                        raise AssertionError(f"slice-major buffers of a streamed shard (cuts {cuts}, {nsl} slices)")
+                else:
+                    check_final(finc, o_fin, f"streamed chunks {cuts} through a summary table")
+                ctx.set_tuning(0)
+                if ctx.flags():
+                    raise AssertionError("kernel flags after the streamed chunks")
+                n["streamed"] = n.get("streamed", 0) + 1
+            # ---- round 5: position ranges inside the library (uint16, listed-once panels split; everything else runs whole behind a join) ----
+            if rng.random() < 0.3:
+                ctx.set_tuning(1, groups=1)
+                ctx.set_ranges(int(rng.integers(2, 5)))
+                finr = ctx.error_estimate(dev, P, C_value, cov, E=E, dup_off=d_dup)
+                finr = ctx.error_estimate(dev, P, C_value, cov, E=E, dup_off=d_dup, out=finr)
+                ctx.set_ranges(1)
+                ctx.set_tuning(0)
+                check_final(finr, o_fin, "error_estimate over position ranges")
+                n["ranges"] = n.get("ranges", 0) + 1
             # ---- sliced merge over a random number of shards ----
             if S >= 2:
                 nsh = int(rng.integers(2, min(S, 8) + 1))
@@ -161,10 +210,11 @@ def main():
             exp = orc.poisson_call(trecs, P, thr, ref_code, cov, E=E, ext_pos=ext_pos if E else None)
             td, fits = ctx.pack(t(trecs), layout)
             assert fits
-            for mode in (POISSON_PREFILTER, POISSON_FULL):
+            for mode in (POISSON_PREFILTER, POISSON_FULL, POISSON_PREFILTER):
                 kw = dict(mode=mode, E=E, ext_pos=t(ext_pos) if E else None, dense_q=(mode == POISSON_FULL),
                           capacity=max(1 << 12, 32 * (P + E) * T * 4))
                 ctx.flags()
+                ctx.set_ranges(int(rng.integers(2, 5)) if mode == POISSON_PREFILTER and rng.random() < 0.5 else 1)
                 res = ctx.poisson_call(td, P, t(thr), t(ref_code), cov, **kw)
                 if ctx.flags() & 4:  # more survivors than the default queue holds: size it for the worst case, as the CLI does
                     ctx.set_queue_items((P + E) * T * 3)
@@ -184,6 +234,7 @@ def main():
                     if not (np.array_equal(q == -1, exp["q"] == -1) and np.max(np.abs(q - exp["q"])) <= 1e-5):
                         raise AssertionError("dense Q")
                 calls = ctx.read_calls(res)
+                ctx.set_ranges(1)
                 if len(calls) != sum(bin(int(v)).count("1") for v in exp["call_mask"].ravel()):
                     raise AssertionError(f"call list length, mode {mode}")
             n["poisson"] += 1
