@@ -946,27 +946,49 @@ int run_variant_calling(const VcArgs &a)
             }
         }
         const double t2 = now_s();
-        // Calls within rounding of a gate.  The device forms Q in fp64 with ROCm's exp / log, the reference with glibc and an
-        // x87 long double log10 (VC:3866-3880); they agree to ~1e-10, so a pair whose device Q lies within 1e-6 of the call
-        // gate Q >= 5 (VC:898; flagged by the kernel, listed either way) or of the LowQ threshold Q < 20 (VC:1023) is
-        // re-evaluated here with the reference's own operation sequence before it is gated, flagged or printed.
-        int64_t n_guarded = 0, n_dropped = 0;
+        // Every emitted pair is scored once more here, with the reference's own operation sequence (score_reference_sequence:
+        // kf_gammaq in double with the host's libm, the final log10 in x87 long double, VC:3834-3884), before it is gated,
+        // flagged or printed: the device forms Q in fp64 with ROCm's exp / log and agrees to ~1e-10, which decides every pair
+        // that is not within 1e-6 of the call gate Q >= 5 (VC:898; those are flagged by the kernel and listed either way) or of
+        // the LowQ threshold Q < 20 (VC:1023) -- and since round 5 the PRINTED digits are the host's too, so that no column of
+        // the Summary or the VCFs depends on the device's libm.  Sparse (0.1 % of the records), a few threads.
+        int64_t n_guarded = 0, n_dropped = 0, n_dropped_unflagged = 0;
         {
             PhaseClock::Scope sc("guard_and_sort");
+            std::vector<long double> qf(rows.size()), qb(rows.size());
+            {
+                int nt_g = (int)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, rows.size() / 256));
+                if (const char *e = getenv("AMPLISOLVE_THREADS")) nt_g = std::max(1, std::min(nt_g, atoi(e)));
+                auto score = [&](int tid) {
+                    for (size_t i = rows.size() * (size_t)tid / (size_t)nt_g, i1 = rows.size() * (size_t)(tid + 1) / (size_t)nt_g; i < i1; ++i) {
+                        const CallRow &c = rows[i];
+                        qf[i] = score_reference_sequence(c.k_fw, c.rd - c.bw, thr[(size_t)(0 * 4 + c.alt) * P + c.p]); // VC:895
+                        qb[i] = score_reference_sequence(c.k_bw, c.bw, thr[(size_t)(1 * 4 + c.alt) * P + c.p]);        // VC:896
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nt_g; ++t) th.emplace_back(score, t);
+                score(0);
+                for (auto &t : th) t.join();
+            }
             std::vector<CallRow> kept;
             kept.reserve(rows.size());
-            for (CallRow &c : rows) {
+            for (size_t i = 0; i < rows.size(); ++i) {
+                CallRow &c = rows[i];
                 auto near = [](double q, double gate) { return std::fabs(q - gate) <= AMPLI_CALL_GATE_EPS; };
-                if ((c.flags & AMPLI_CALL_BORDERLINE) || near(c.q_fw, 20) || near(c.q_bw, 20)) {
-                    ++n_guarded;
-                    const long double qf = score_reference_sequence(c.k_fw, c.rd - c.bw, thr[(size_t)(0 * 4 + c.alt) * P + c.p]); // VC:895
-                    const long double qb = score_reference_sequence(c.k_bw, c.bw, thr[(size_t)(1 * 4 + c.alt) * P + c.p]);        // VC:896
-                    if (!(qf >= 5 && qb >= 5)) { ++n_dropped; continue; } // VC:898 in the reference's own arithmetic
-                    c.q_fw = (double)qf;
-                    c.q_bw = (double)qb;
+                const bool flagged = (c.flags & AMPLI_CALL_BORDERLINE) || near(c.q_fw, 20) || near(c.q_bw, 20);
+                n_guarded += flagged ? 1 : 0;
+                if (!(qf[i] >= 5 && qb[i] >= 5)) { // VC:898 in the reference's own arithmetic
+                    ++n_dropped;
+                    n_dropped_unflagged += flagged ? 0 : 1; // would mean device and host differ by more than the guard's 1e-6: reported below
+                    continue;
                 }
+                c.q_fw = (double)qf[i];
+                c.q_bw = (double)qb[i];
                 kept.push_back(c);
             }
+            if (n_dropped_unflagged)
+                std::cerr << "warning: " << n_dropped_unflagged << " pair(s) passed the device's gate by more than 1e-6 and fail the host's; the host's arithmetic decides" << std::endl;
             rows.swap(kept);
             // emission order: samples in visit order, lines in file order, alts in A,C,G,T order (VC:672, 723, 869-3283)
             std::sort(rows.begin(), rows.end(), [](const CallRow &x, const CallRow &y) {
