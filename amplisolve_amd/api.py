@@ -174,7 +174,7 @@ class Context:
         """the kernel the latest error_reduce launch of this context was"""
         k = self.lib.ampli_last_reduce_kernel(self.h)
         self._check(min(k, 0))
-        return "error_reduce_u16_kernel" if k == 1 else "error_reduce_kernel"
+        return {1: "error_reduce_u16_kernel", 2: "error_reduce_u24_kernel"}.get(k, "error_reduce_kernel")
 
     # ---- hipGraph capture ---------------------------------------------------------------
     def graph_begin(self):
@@ -210,9 +210,9 @@ class Context:
         """record `ev` on range `rng`'s stream without closing the section (ampli_range_event_record)"""
         self._check(self.lib.ampli_range_event_record(self.h, rng, ev))
 
-    def set_reduce_compact(self, on: bool):
-        """error_estimate on uint16 records through the compact-state kernel (five waves per SIMD) where its shape applies; same results"""
-        self._check(self.lib.ampli_set_reduce_compact(self.h, int(bool(on))))
+    def set_reduce_compact(self, on):
+        """True / False; 2 = the compact-state kernel for uint16 records only (A/B runs of its 24-bit form)"""
+        self._check(self.lib.ampli_set_reduce_compact(self.h, 2 if on == 2 else int(bool(on))))
 
     def set_slice_format(self, slim: bool):
         """sums of the sliced exchange as 14 packed planes (slim) or 21 plain ones (ampli_set_slice_format)"""

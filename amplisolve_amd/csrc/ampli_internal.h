@@ -35,7 +35,8 @@ struct ampli_ctx {
     int reduce_splits = 0; // 0 = auto
     int reduce_groups = 0;  // lane groups per wave in error_reduce: 0 = auto, else 1, 2 or 4
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
-    int last_reduce_kernel = -1; // 0 general, 1 compact (ampli_last_reduce_kernel)
+    int last_reduce_kernel = -1; // 0 general, 1 compact uint16, 2 compact 24-bit (ampli_last_reduce_kernel)
+    int reduce_compact_u16_only = 0; // ampli_set_reduce_compact(ctx, 2)
     int reduce_compact = 1; // 1 = error_reduce_u16_kernel (compact state, five waves per SIMD) where its shape applies (ampli_set_reduce_compact)
     int grp_size = 1, grp_index = 0; // sliced exchange buffers hold grp_size batches per slice chunk; calls address batch grp_index
     int slice_fmt = 0;               // AMPLI_SLICE_WIDE / AMPLI_SLICE_SLIM: what the sums of the sliced exchange look like (ampli_set_slice_format)

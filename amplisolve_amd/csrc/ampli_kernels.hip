@@ -387,6 +387,7 @@ extern "C" int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on)
 {
     if (!ctx) return AMPLI_E_INVALID;
     ctx->reduce_compact = on ? 1 : 0;
+    ctx->reduce_compact_u16_only = on == 2 ? 1 : 0; // 2: the compact-state kernel for uint16 records only (A/B runs of the 24-bit form)
     return AMPLI_OK;
 }
 
@@ -1205,6 +1206,9 @@ struct Fast16 {
     unsigned long long zmask[4], lmask[4]; // wave masks (scalar registers): no first record yet | a later one met
 };
 
+// DEPTH_CHECK (24-bit records): a covered record with RD >= FAST_COUNT_LIMIT raises the lane's "beyond the fast envelope" bit (the 24-bit
+// cross products and the 32-bit depth sums stop being exact there); a uint16 record's RD is below 2^19 by construction.
+template <bool DEPTH_CHECK>
 __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1, const float C, const int cov)
 {
     const bool present = r0.x != AMPLI_ABSENT;
@@ -1218,6 +1222,7 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
     const unsigned long long covmask = __builtin_amdgcn_sicmp(min(FW, BW), cov, 39 /*sge*/);
     a.nrec_bad += present ? 1u : 0u;               // EE:1659
     if (covmask == 0) return;
+    if (DEPTH_CHECK) a.nrec_bad |= (min(FW, BW) >= cov && (unsigned)RD >= (unsigned)FAST_COUNT_LIMIT) ? 0x80000000u : 0u;
     // RD < 2^19 for uint16 records: never beyond FAST_COUNT_LIMIT; the bit stays for the records-per-lane check
     // ampli_af_limit(d) as one float multiply (ampli_math.h): the same integer for every d < 2^24, and the floats are needed anyway
     const float fFW = (float)FW, fBW = (float)BW, fRD = (float)RD;
@@ -1386,14 +1391,18 @@ __device__ __forceinline__ void part16_store(const AccPtrs &t, const long long P
 // such tiles inside this kernel -- correct, but the second loop costs the first one two registers it does not have (spill
 // stores inside the row loop of EVERY tile of the cohort).
 // TAB: the launch reads and / or writes the accumulator table (a streamed cohort's chunks); without it the epilogue is the headline's.
-template <bool DUP, bool TAB>
-__global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView rv, const long long P, const long long p_lo, const long long p_hi,
-                                                                  const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
-                                                                  const float C, const int cov, int *__restrict__ flags, const AccPtrs tab,
-                                                                  const FinOut fin)
+// LAY: AMPLI_RECORDS_U16, or (round 5) AMPLI_RECORDS_U24 -- the same state fits 24-bit records as long as a covered record's RD stays
+// below FAST_COUNT_LIMIT = 2^22 (checked per record) and a lane takes at most COMPACT_MAX_REC_U24 = 1023 records: a strand depth sum
+// is then < 2^22 x 1023 < 2^32 (kept and widened as unsigned), a sum of X < 0.05 x 2^22 x 1023 < 2^28, a count < 2^16.
+constexpr int COMPACT_MAX_REC_U24 = 1023;
+template <int LAY, bool DUP, bool TAB>
+__device__ __forceinline__ void compact_reduce_body(Red16Shared &sh, const RecView &rv, const long long P, const long long p_lo, const long long p_hi,
+                                                    const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
+                                                    const float C, const int cov, int *__restrict__ flags, const AccPtrs &tab,
+                                                    const FinOut &fin)
 {
-    __shared__ Red16Shared sh;
-    constexpr int RB = 16;
+    constexpr int RB = rec_bytes_of<LAY>();
+    constexpr bool DC = LAY != AMPLI_RECORDS_U16;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long p_raw = p_lo + (long long)blockIdx.x * 64 + lane;
@@ -1419,40 +1428,40 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
     // at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none; that form ran
     // at 166 us on config 3 against the general kernel's 124; two sets, one row in flight: 107; three: 102.)  Past the end of
     // the chunk the loads stay on its last row (cache hits) and the rows are not visited.
-    RawRec<AMPLI_RECORDS_U16> ra = rec_load_at<AMPLI_RECORDS_U16>(q), rb, rc;
+    RawRec<LAY> ra = rec_load_at<LAY>(q), rb, rc;
     if (s0 + 1 < s1) q += row_step;
-    rb = rec_load_at<AMPLI_RECORDS_U16>(q);
+    rb = rec_load_at<LAY>(q);
     for (int s = s0; s < s1; s += 3) {
         if (s + 2 < s1) q += row_step;
-        rc = rec_load_at<AMPLI_RECORDS_U16>(q);
+        rc = rec_load_at<LAY>(q);
         {
             int4 c0, c1;
-            rec_decode<AMPLI_RECORDS_U16>(ra, c0, c1);
-            if (s < s1) visit16(f, c0, c1, C, cov);
+            rec_decode<LAY>(ra, c0, c1);
+            if (s < s1) visit16<DC>(f, c0, c1, C, cov);
         }
         if (s + 3 < s1) q += row_step;
-        ra = rec_load_at<AMPLI_RECORDS_U16>(q);
+        ra = rec_load_at<LAY>(q);
         {
             int4 c0, c1;
-            rec_decode<AMPLI_RECORDS_U16>(rb, c0, c1);
-            if (s + 1 < s1) visit16(f, c0, c1, C, cov);
+            rec_decode<LAY>(rb, c0, c1);
+            if (s + 1 < s1) visit16<DC>(f, c0, c1, C, cov);
         }
         if (s + 4 < s1) q += row_step;
-        rb = rec_load_at<AMPLI_RECORDS_U16>(q);
+        rb = rec_load_at<LAY>(q);
         {
             int4 c0, c1;
-            rec_decode<AMPLI_RECORDS_U16>(rc, c0, c1);
-            if (s + 2 < s1) visit16(f, c0, c1, C, cov);
+            rec_decode<LAY>(rc, c0, c1);
+            if (s + 2 < s1) visit16<DC>(f, c0, c1, C, cov);
         }
     }
-    if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)FAST_MAX_RECORDS) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
+    if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)(DC ? COMPACT_MAX_REC_U24 : FAST_MAX_RECORDS) || (DC && (f.nrec_bad >> 31))) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
     Part16 a;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             a.snt[st][nt] = (double)f.sx[st][nt] + f.sp[st][nt];
-            a.srd[st][nt] = (long long)f.sd[st][nt];
+            a.srd[st][nt] = (long long)(unsigned)f.sd[st][nt];
         }
         // qualifying records of the chunk, saturated at two: every reader asks "none, one, or more" (lane_acc_merge's sums keep that)
         const bool none = (f.zmask[nt] >> lane) & 1, later = (f.lmask[nt] >> lane) & 1;
@@ -1487,6 +1496,26 @@ __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView 
             }
         }
     }
+}
+
+template <bool DUP, bool TAB>
+__global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView rv, const long long P, const long long p_lo, const long long p_hi,
+                                                                  const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
+                                                                  const float C, const int cov, int *__restrict__ flags, const AccPtrs tab,
+                                                                  const FinOut fin)
+{
+    __shared__ Red16Shared sh;
+    compact_reduce_body<AMPLI_RECORDS_U16, DUP, TAB>(sh, rv, P, p_lo, p_hi, dup_off, S, chunk_len, C, cov, flags, tab, fin);
+}
+
+template <bool DUP, bool TAB>
+__global__ __launch_bounds__(256, 5) void error_reduce_u24_kernel(const RecView rv, const long long P, const long long p_lo, const long long p_hi,
+                                                                  const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
+                                                                  const float C, const int cov, int *__restrict__ flags, const AccPtrs tab,
+                                                                  const FinOut fin)
+{
+    __shared__ Red16Shared sh;
+    compact_reduce_body<AMPLI_RECORDS_U24, DUP, TAB>(sh, rv, P, p_lo, p_hi, dup_off, S, chunk_len, C, cov, flags, tab, fin);
 }
 
 // dst = parts[0] (+) parts[1] (+) ... in order; parts are tables at base + i*stride
@@ -2494,8 +2523,9 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
     const bool fast = !ctx->reduce_general && !co.rv.rd && !co.rv.rd_ext; // lines with their own RD column: the literal kernel
     // the shape error_reduce_u16_kernel takes (below).  From one tile per CU on it beats every cut of the general kernel along
     // lanes or samples (tools/sweep_tiles.py: 48 us against 62 at 768 tiles, 69 against 102 at 1280), so such a launch is not cut
-    const bool compact_shape = ctx->reduce_compact && fast && co.layout == AMPLI_RECORDS_U16 && (!d_acc || fin.summary) && !fin.packed &&
-                               S <= RED_WAVES * FAST_MAX_CHUNK;
+    const bool compact_shape = ctx->reduce_compact && fast && (!d_acc || fin.summary) && !fin.packed &&
+                               ((co.layout == AMPLI_RECORDS_U16 && S <= RED_WAVES * FAST_MAX_CHUNK) ||
+                                (co.layout == AMPLI_RECORDS_U24 && S <= RED_WAVES * COMPACT_MAX_REC_U24 && !ctx->reduce_compact_u16_only));
     const bool compact_uncut = compact_shape && (P + 63) / 64 >= ctx->n_cu;
     int G = ctx->reduce_groups;
     if (G != 1 && G != 2 && G != 4) {
@@ -2539,14 +2569,19 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         kfin.accumulate = 0;   // folded in by the merge kernel, below
     }
     if (splits > 65535 || tiles > 0x7fffffffll) return fail(ctx, AMPLI_E_RANGE, "error_reduce: panel or sample count beyond the grid limits");
-    ctx->last_reduce_kernel = compact_shape && G == 1 && splits == 1;
+    ctx->last_reduce_kernel = (compact_shape && G == 1 && splits == 1) ? (co.layout == AMPLI_RECORDS_U24 ? 2 : 1) : 0;
     if (ctx->last_reduce_kernel) {
         AccPtrs tab = {};
         if (d_acc) tab = to_ptrs(d_acc);
         const int clen = (S + RED_WAVES - 1) / RED_WAVES;
-#define AMPLI_LAUNCH_U16(DUPV, TABV, ST, LO, HI)                                                                                                   \
-    hipLaunchKernelGGL((error_reduce_u16_kernel<DUPV, TABV>), dim3((unsigned)(((HI) - (LO) + 63) / 64)), dim3(256), 0, ST, co.rv, (long long)P,      \
+#define AMPLI_LAUNCH_CK(KERNEL, DUPV, TABV, ST, LO, HI)                                                                                            \
+    hipLaunchKernelGGL((KERNEL<DUPV, TABV>), dim3((unsigned)(((HI) - (LO) + 63) / 64)), dim3(256), 0, ST, co.rv, (long long)P,                      \
                        (long long)(LO), (long long)(HI), d_dup_off, (int)S, clen, C, (int)cov, ctx->d_flags, tab, fin)
+#define AMPLI_LAUNCH_U16(DUPV, TABV, ST, LO, HI)                                                                                                   \
+    do {                                                                                                                                           \
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_CK(error_reduce_u24_kernel, DUPV, TABV, ST, LO, HI);                                      \
+        else AMPLI_LAUNCH_CK(error_reduce_u16_kernel, DUPV, TABV, ST, LO, HI);                                                                     \
+    } while (0)
         if (E > 0) {
             // the tiles with a position listed more than once go to the general kernel (at most one such tile per extra slot)
             hipStream_t st = main_stream(ctx);
@@ -2559,9 +2594,12 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
             if (d_acc) AMPLI_LAUNCH_U16(true, true, st, 0, P); else AMPLI_LAUNCH_U16(true, false, st, 0, P);
             int rcc = check_launch(ctx, "error_reduce_u16_kernel");
             if (rcc) return rcc;
-            hipLaunchKernelGGL((error_reduce_kernel<true, 1, AMPLI_RECORDS_U16>), dim3((unsigned)std::min<long long>(E, ntiles)), dim3(256), 0, st,
-                               co.rv, (long long)P, (long long)E, d_dup_off, (int)S, (int)first_sample, clen, C, (int)cov, d_acc ? (char *)d_acc->snt : (char *)nullptr,
-                               (size_t)0, off[0], off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, fin, (const unsigned *)list);
+#define AMPLI_LAUNCH_DUPTILES(LV)                                                                                                                   \
+    hipLaunchKernelGGL((error_reduce_kernel<true, 1, LV>), dim3((unsigned)std::min<long long>(E, ntiles)), dim3(256), 0, st, co.rv, (long long)P,    \
+                       (long long)E, d_dup_off, (int)S, (int)first_sample, clen, C, (int)cov, d_acc ? (char *)d_acc->snt : (char *)nullptr, (size_t)0, \
+                       off[0], off[1], off[2], off[3], off[4], off[5], off[6], off[7], ctx->d_flags, fin, (const unsigned *)list)
+            if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_DUPTILES(AMPLI_RECORDS_U24); else AMPLI_LAUNCH_DUPTILES(AMPLI_RECORDS_U16);
+#undef AMPLI_LAUNCH_DUPTILES
             return check_launch(ctx, "error_reduce_kernel (tiles with positions listed more than once)");
         }
         if (ranges_apply(ctx, P)) { // position ranges on concurrent streams (ampli_set_ranges)
@@ -2578,6 +2616,7 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         hipStream_t st = main_stream(ctx);
         if (d_acc) AMPLI_LAUNCH_U16(false, true, st, 0, P); else AMPLI_LAUNCH_U16(false, false, st, 0, P);
 #undef AMPLI_LAUNCH_U16
+#undef AMPLI_LAUNCH_CK
         return check_launch(ctx, "error_reduce_u16_kernel");
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);

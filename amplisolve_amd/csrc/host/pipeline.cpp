@@ -612,7 +612,7 @@ int run_error_estimation(const EeArgs &a)
             for (void *b : xbufs)
                 if (!b) throw Error{AMPLI_E_INVALID, "shard hook ee_buffers returned a null buffer"};
         }
-        int launches_compact = 0, launches_general = 0;
+        int launches_compact = 0, launches_compact24 = 0, launches_general = 0;
         void *ev = nullptr;
         dev.check(dev.api->event_create(&ev), "ampli_event_create");
         struct EvGuard { const HipApi *api; void *ev; ~EvGuard() { if (ev) api->event_destroy(ev); } } evg{dev.api, ev};
@@ -653,7 +653,8 @@ int run_error_estimation(const EeArgs &a)
                                                                     fuse ? d_rate : nullptr, fuse ? d_code : nullptr, nullptr, fuse ? d_germ : nullptr,
                                                                     fuse ? d_gp : nullptr, fuse ? d_flags : nullptr), "ampli_error_reduce_records");
                         dev.check(dev.api->event_record(dev.ctx, ev), "ampli_event_record");
-                        (dev.api->last_reduce_kernel(dev.ctx) == 1 ? launches_compact : launches_general) += 1;
+                        const int which = dev.api->last_reduce_kernel(dev.ctx); // 1 / 2: the compact-state kernel for uint16 / 24-bit records
+                        (which == 1 ? launches_compact : which == 2 ? launches_compact24 : launches_general) += 1;
                     }
                     const double w0 = now_s();
                     {
@@ -745,8 +746,10 @@ int run_error_estimation(const EeArgs &a)
         if (getenv("AMPLISOLVE_TIMING"))
             std::cerr << "TIMING panel " << t1 - t0 << "\nTIMING stream " << t2 - t1 << " lines " << n_lines << " chunks " << chunks_done
                       << " parse_busy " << parse_s << " device_wait " << wait_s << " record_MB " << rec_bytes_up / 1e6 << "\nTIMING finish " << t3 - t2 << "\nTIMING write " << t4 - t3
-                      // which error_reduce kernel each chunk's launch was (ampli_last_reduce_kernel): error_reduce_u16_kernel (compact state) / error_reduce_kernel
-                      << "\nTIMING reduce_launches " << launches_compact + launches_general << " error_reduce_u16_kernel " << launches_compact << " error_reduce_kernel " << launches_general
+                      // which error_reduce kernel each chunk's launch was (ampli_last_reduce_kernel): error_reduce_u16_kernel / error_reduce_u24_kernel
+                      // (compact state) / error_reduce_kernel
+                      << "\nTIMING reduce_launches " << launches_compact + launches_compact24 + launches_general << " error_reduce_u16_kernel " << launches_compact
+                      << " error_reduce_u24_kernel " << launches_compact24 << " error_reduce_kernel " << launches_general
                       << " accumulator_table " << (have_acc ? 1 : 0) << std::endl;
         std::cout << "\n" << kLine << std::endl;
         return 0;

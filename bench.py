@@ -197,6 +197,7 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                                  "chunks": int(ee_t.get("stream.chunks", 0)),
                                  # which error_reduce kernel each chunk's launch was (ampli_last_reduce_kernel, printed by the executable)
                                  "reduce_launches": {"error_reduce_u16_kernel": int(ee_t.get("reduce_launches.error_reduce_u16_kernel", 0)),
+                                                     "error_reduce_u24_kernel": int(ee_t.get("reduce_launches.error_reduce_u24_kernel", 0)),
                                                      "error_reduce_kernel": int(ee_t.get("reduce_launches.error_reduce_kernel", 0)),
                                                      "accumulator_table": bool(ee_t.get("reduce_launches.accumulator_table", 0))},
                                  # where the wall time goes: the phase clock of the executable (csrc/host/pipeline.cpp PhaseClock).
@@ -547,7 +548,7 @@ def main():
     # position ranges inside the library (N = 1): the kernels of a pass are then several launches on several streams, timed by events
     # on each range's own stream (ampli_range_event_record: does not close the section)
     n_ranges = args.ranges if (args.split_ranges and not multi and args.streams <= 1 and mode == POISSON_PREFILTER and not args.async_drain) else 1
-    if n_ranges > 1 and ((P + 63) // 64 < 2 * n_ranges or P % 4 != 0 or layout != "u16"):
+    if n_ranges > 1 and ((P + 63) // 64 < 2 * n_ranges or P % 4 != 0 or layout == "i32"):
         n_ranges = 1  # the library would run such launches whole (include/amplisolve_hip.h, ampli_set_ranges)
     evr = {i: [[ctx.event() for _ in range(3)] for _ in range(n_ranges)] for i in ev_steps} if n_ranges > 1 else None
 
@@ -994,7 +995,7 @@ def main():
         try:
             kname = ctx.last_reduce_kernel()
             # workgroups a CU holds: 96 VGPRs -> five waves per SIMD (compact kernel), 120 -> four (general); one wave of each of a CU's SIMDs per workgroup
-            per_round = torch.cuda.get_device_properties(dev_index).multi_processor_count * (5 if kname == "error_reduce_u16_kernel" else 4)
+            per_round = torch.cuda.get_device_properties(dev_index).multi_processor_count * (5 if kname in ("error_reduce_u16_kernel", "error_reduce_u24_kernel") else 4)
             P2 = per_round * args.whole_rounds * 64
             an2 = ctx.synth_fill(P2, S, seed=SEED, depth=depth)
             if layout != "i32":

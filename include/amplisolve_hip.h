@@ -475,15 +475,17 @@ int ampli_pileup_count(ampli_ctx *ctx, const uint8_t *d_bam, const uint64_t *d_r
  * kernel that follows the reference operation by operation for any depth (slower).  reduce_lane_groups: lane
  * groups per wave of error_reduce (1, 2 or 4; 0 = automatic: 1 unless the panel is too small to fill the chip). */
 int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduce_general, int32_t reduce_lane_groups);
-/* error_reduce for uint16 records with a compact per-position state (96 VGPRs: five waves per SIMD instead of four): taken by
+/* error_reduce with a compact per-position state (96 VGPRs: five waves per SIMD instead of four) -- error_reduce_u16_kernel for
+ * uint16 records (at most 4096 samples per launch) and, since round 5, error_reduce_u24_kernel for 24-bit records (at most 4092
+ * samples; a covered record with RD >= 2^22 raises AMPLI_FLAG_RERUN_GENERAL like the fast general kernel): taken by
  * ampli_error_estimate / ampli_error_reduce_records(_sliced) / ampli_error_reduce_sliced when on != 0 (the default) and the launch
- * has the shape it covers -- fast kernel, uint16 records, one lane group, one sample split, at most 4096 samples, and either no
- * accumulator table (finalize fused, or the shard's sums straight into the sliced exchange buffers) or a table the caller takes
- * as streaming state (AMPLI_REDUCE_SUMMARY).  Positions listed more than once (E > 0) are served: their tiles walk sample by
- * sample, primary record then extras.  Every other launch takes the general kernel.  Same results, bit for bit. */
+ * has the shape they cover -- fast kernel, one lane group, one sample split, and either no accumulator table (finalize fused, or
+ * the shard's sums straight into the sliced exchange buffers) or a table the caller takes as streaming state
+ * (AMPLI_REDUCE_SUMMARY).  Positions listed more than once (E > 0) are served: their tiles go to the general kernel over a list.
+ * Every other launch takes the general kernel.  Same results, bit for bit.  on = 2: the uint16 form only (A/B runs). */
 int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
-/* Which kernel the context's latest error_reduce launch was: 0 = error_reduce_kernel (general), 1 = error_reduce_u16_kernel
- * (compact state); AMPLI_E_INVALID before the first launch.  For tests and the bench line, which name the kernel they measured. */
+/* Which kernel the context's latest error_reduce launch was: 0 = error_reduce_kernel (general), 1 = error_reduce_u16_kernel,
+ * 2 = error_reduce_u24_kernel (compact state); AMPLI_E_INVALID before the first launch.  For tests and the bench line, which name the kernel they measured. */
 int ampli_last_reduce_kernel(const ampli_ctx *ctx);
 
 /*

@@ -12,7 +12,7 @@ from tests.test_gpu_records import _pack
 
 pytestmark = pytest.mark.gpu
 ABSENT = np.iinfo(np.int32).min
-COMPACT, GENERAL = "error_reduce_u16_kernel", "error_reduce_kernel"
+COMPACT, GENERAL = {"u16": "error_reduce_u16_kernel", "u24": "error_reduce_u24_kernel"}, "error_reduce_kernel"
 
 
 def _cohort(P, S, rng, dup_frac=8, triple_frac=50, runs=True):
@@ -54,8 +54,9 @@ def _summary_equal(acc, ref):
     assert np.all(pl["gm_first"][~m1] == np.iinfo(np.int32).max)
 
 
+@pytest.mark.parametrize("lay", ["u16", "u24"])
 @pytest.mark.parametrize("P,S", [(1, 1), (64, 3), (65, 4), (130, 9), (1000, 33), (4097, 37), (777, 130), (20000, 64), (300, 700)])
-def test_positions_listed_more_than_once_through_the_compact_kernel(ctx, P, S):
+def test_positions_listed_more_than_once_through_the_compact_kernel(ctx, P, S, lay):
     """E > 0: the compact kernel keeps every tile of positions listed once; the tiles that hold a position listed twice or more go,
     whole, to error_reduce_kernel over dup_tiles_kernel's list.  Same table as the oracle and as the general kernel alone."""
     import torch
@@ -63,16 +64,16 @@ def test_positions_listed_more_than_once_through_the_compact_kernel(ctx, P, S):
     rng = np.random.default_rng(P * 7 + S)
     recs, E, dup_off = _cohort(P, S, rng)
     want = orc.error_finalize(orc.error_reduce(recs, P, 0.002, 100, E=E, dup_off=dup_off))
-    ctx.set_record_layout("u16")
+    ctx.set_record_layout(lay)
     try:
-        packed = _pack(ctx, recs, "u16")
+        packed = _pack(ctx, recs, lay)
         outs = []
         for compact in (True, False):
             ctx.set_reduce_compact(compact)
             ctx.set_tuning(1 if compact else 0, groups=1 if compact else 0)
             got = ctx.error_estimate(packed, P, 0.002, 100, E=E, dup_off=_t(dup_off))
             assert ctx.flags() == 0
-            assert ctx.last_reduce_kernel() == (COMPACT if compact else GENERAL)
+            assert ctx.last_reduce_kernel() == (COMPACT[lay] if compact else GENERAL)
             assert_final_equal(got, want)
             outs.append(got)
         for k in ("rate", "thr", "code", "germ_present"):
@@ -85,7 +86,7 @@ def test_positions_listed_more_than_once_through_the_compact_kernel(ctx, P, S):
 
 @pytest.mark.parametrize("P,S,cuts,extras", [(300, 13, (0, 13), True), (300, 13, (0, 1, 2, 13), True), (1000, 40, (0, 7, 8, 29, 40), False),
                                              (4097, 37, (0, 16, 32, 37), True), (20000, 96, (0, 32, 64, 96), False), (65, 600, (0, 300, 600), True)])
-@pytest.mark.parametrize("mix", ["compact", "general_first", "general_last"])
+@pytest.mark.parametrize("mix", ["compact", "general_first", "general_last", "u24_compact"])
 def test_streamed_chunks_through_the_compact_kernel(ctx, P, S, cuts, extras, mix):
     """What AmpliSolveErrorEstimation launches: a uint16 cohort in chunks of consecutive samples, each chunk its own buffers, folded
     into ONE table taken as streaming state; the last launch finalises.  Every launch is the compact kernel (asserted); with `mix`
@@ -114,12 +115,14 @@ def test_streamed_chunks_through_the_compact_kernel(ctx, P, S, cuts, extras, mix
             ext[:, :, 0] = ABSENT
             if E:
                 ext[:, :E] = chunk[:, P:]
-            rec = ctx.records(_pack(ctx, prim, "u16"), "u16", hi - lo, E=E, row_stride=stride, ext=_pack(ctx, ext, "u16"), ext_stride=max(E, 1) + 2,
+            # "u24_compact": every other chunk arrives in 24-bit records (a chunk whose counts need them): the two compact kernels share the table
+            lay = "u24" if (mix == "u24_compact" and ci % 2 == 1) else "u16"
+            rec = ctx.records(_pack(ctx, prim, lay), lay, hi - lo, E=E, row_stride=stride, ext=_pack(ctx, ext, lay), ext_stride=max(E, 1) + 2,
                               dup_off=_t(dup_off))
             general = n_chunks > 1 and ((mix == "general_first" and ci == 0) or (mix == "general_last" and ci == n_chunks - 1))
             ctx.set_reduce_compact(not general)
             fin = ctx.error_reduce_records(rec, P, acc, 0.002, 100, first_sample=lo, accumulate=ci > 0, finalize=ci == n_chunks - 1, summary=True)
-            assert ctx.last_reduce_kernel() == (GENERAL if general else COMPACT)
+            assert ctx.last_reduce_kernel() == (GENERAL if general else COMPACT[lay])
         assert ctx.flags() == 0
     finally:
         ctx.set_reduce_compact(True)
@@ -184,7 +187,7 @@ def test_last_chunk_of_a_shard_goes_slice_major(ctx, P, S, n, cuts, extras, slim
                 ctx.error_reduce_records_sliced(rec, P, acc, n, got_s, got_g, first_sample=5 + lo, accumulate=ci > 0)
             else:
                 ctx.error_reduce_records(rec, P, acc, 0.002, 100, first_sample=5 + lo, accumulate=ci > 0, summary=True)
-            assert ctx.last_reduce_kernel() == COMPACT
+            assert ctx.last_reduce_kernel() == COMPACT["u16"]
         assert ctx.flags() == 0
         assert torch.equal(got_s.view(torch.int64), want_s.view(torch.int64))
         assert torch.equal(got_g.view(torch.int32), want_g.view(torch.int32))

@@ -107,14 +107,14 @@ def main():
             general = bool(rng.random() < 0.3)
             groups = int(rng.choice([0, 1, 2, 4]))
             splits = int(rng.choice([0, 0, 1, 2, 3]))
-            if u16 and rng.random() < 0.5:
+            if layout != "i32" and rng.random() < 0.5:
                 general, groups, splits = False, 1, 1  # the shape error_reduce_u16_kernel takes (the fused estimate below); with E > 0 its tiles
                                                        # of positions listed more than once go to the general kernel over the tile list
             ctx.set_tuning(splits, general=general, groups=groups)
             acc = ctx.error_reduce(dev, P, C_value, cov, E=E, dup_off=d_dup)
             fin2 = ctx.error_finalize(acc, C_value, cov)
             fin1 = ctx.error_estimate(dev, P, C_value, cov, E=E, dup_off=d_dup)
-            n["compact_kernel"] = n.get("compact_kernel", 0) + (ctx.last_reduce_kernel() == "error_reduce_u16_kernel")
+            n["compact_kernel"] = n.get("compact_kernel", 0) + (ctx.last_reduce_kernel() in ("error_reduce_u16_kernel", "error_reduce_u24_kernel"))
             ctx.set_tuning(0)
             flags = ctx.flags()
             if flags & 2:

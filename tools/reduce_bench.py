@@ -22,7 +22,7 @@ for name, rb in [(n, {"u24": 24, "i32": 32, "u16": 16}[n]) for n in (sys.argv[1:
     ctx.set_record_layout(name)
     # RB_SPLITS / RB_ROWS / RB_DRAIN: ampli_set_tuning / ampli_set_poisson_tuning knobs for A/B runs (0 = automatic)
     ctx.set_tuning(int(os.environ.get("RB_SPLITS", "0")))
-    ctx.set_reduce_compact(os.environ.get("RB_COMPACT", "1") == "1")  # error_reduce_u16_kernel (uint16 records only)
+    ctx.set_reduce_compact(int(os.environ.get("RB_COMPACT", "1")))  # 1: the compact-state kernels (uint16 / 24-bit records); 2: uint16 only; 0: general kernel
     ctx.set_poisson_tuning(int(os.environ.get("RB_ROWS", "0")), int(os.environ.get("RB_DRAIN", "0")))
     fin = ctx.error_estimate(n, P, 0.002, 100)
     res = ctx.poisson_call(t, P, fin.thr, ref_code, 100, capacity=1 << 20)
