@@ -278,7 +278,7 @@ def test_sliced_merge_through_the_compact_kernel(ctx16, P, S, n, slim):
 
 @pytest.mark.parametrize("P,S,T,cut", [(5000, 24, 6, 2496), (20000, 256, 8, 9984), (130, 9, 3, 64)])
 def test_position_ranges_on_two_streams_equal_the_single_pass(ctx16, P, S, T, cut):
-    """bench.py's `two_ranges` block: the panel's positions cut into two tile-aligned ranges, each with its own context, stream and
+    """The range split by hand (round 4's `two_ranges` block of bench.py, tools/split_probe.py): the panel's positions cut into two tile-aligned ranges, each with its own context, stream and
     outputs, reading VIEWS of the same resident arrays (row stride = the whole panel): error table and call mask of the two
     ranges side by side are the single pass's, bit for bit -- and both are the oracle's."""
     import torch
