@@ -111,6 +111,7 @@ HIP_SYMBOLS = {
     "ampli_synth_ref": (C.c_int, [vp, vp, i64, u64]),
     "ampli_set_ranges": (C.c_int, [vp, i32]),
     "ampli_ranges_join": (C.c_int, [vp]),
+    "ampli_ranges_concurrent": (C.c_int, [vp]),
     "ampli_range_event_record": (C.c_int, [vp, i32, vp]),
     "ampli_set_reduce_compact": (C.c_int, [vp, i32]),
     "ampli_last_reduce_kernel": (C.c_int, [vp]),

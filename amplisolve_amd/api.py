@@ -203,6 +203,10 @@ class Context:
         ampli_set_ranges); 1 = off.  The section closes at the next other call on this context."""
         self._check(self.lib.ampli_set_ranges(self.h, n))
 
+    def ranges_concurrent(self) -> bool:
+        """did ampli_set_ranges see every pair of the ranges' streams overlap (different hardware queues)?"""
+        return self.lib.ampli_ranges_concurrent(self.h) == 1
+
     def ranges_join(self):
         self._check(self.lib.ampli_ranges_join(self.h))
 

@@ -20,8 +20,9 @@ struct AmpliQueue {
 };
 // one position range of a context with ranges: its stream, its queue, the event the context's stream waits for when the section closes
 struct AmpliLane {
-    hipStream_t stream = nullptr; // lane 0: unused (the context's stream)
+    hipStream_t stream = nullptr; // created by ampli_set_ranges, range 0's too (the context's own stream only forks and joins)
     hipEvent_t done = nullptr;
+    bool verified = false; // its stream overlaps with every earlier lane's (checked by ampli_set_ranges)
     AmpliQueue q;
 };
 
@@ -43,13 +44,14 @@ struct ampli_ctx {
     int rec_layout = 0;     // record layout of every d_recs / d_trecs argument: AMPLI_RECORDS_I32 / _U16 / _U24
     int *d_flags = nullptr; // device word: AMPLI_FLAG_* raised by kernels of this context
     size_t queue_min_items = 0; // ampli_set_queue_items
-    // Position ranges on concurrent streams (ampli_set_ranges): lane 0 is the context's own stream, lanes 1.. own theirs.  Every lane
-    // has its poisson_call prefilter queue (lane 0's is the only one a context without ranges ever uses).
+    // Position ranges on concurrent streams (ampli_set_ranges): every lane owns its stream.  Every lane has its poisson_call prefilter
+    // queue (lane 0's is the only one a context without ranges ever uses, on the context's stream).
     int n_ranges = 1;
     AmpliLane lanes[AMPLI_MAX_RANGES];
     hipEvent_t ev_fork = nullptr;
-    bool ranges_open = false; // lanes 1.. hold work the context's stream has not waited for yet
+    bool ranges_open = false; // the lanes hold work the context's stream has not waited for yet
     long long ranges_P = 0;   // the panel the open section is cut for
+    int ranges_verified = 0;  // 1: every pair of the lanes' streams was seen to run concurrently (ampli_ranges_concurrent)
     // optional: the drain kernel of poisson_call on a side stream (ampli_set_async_drain)
     int async_drain = 0;
     hipStream_t side = nullptr;

@@ -164,13 +164,18 @@ static void range_cuts(const long long P, const int n, long long cut[AMPLI_MAX_R
     cut[n] = P;
 }
 
-static inline hipStream_t lane_stream(ampli_ctx *ctx, const int k) { return k == 0 ? ctx->stream : ctx->lanes[k].stream; }
+// Every range runs on a stream the context created itself, range 0 included: HIP deals streams to the device's few hardware queues
+// (four by default) in the order of their creation, and two ranges on one queue run one after the other.  Streams created back to
+// back here land on different queues; the caller's stream -- created who knows when -- is only forked from and joined into.
+// (Round 5's first form ran range 0 on the caller's stream: two and three ranges overlapped, four did not -- ranges 2 and 3 took
+// twice the time of ranges 0 and 1, 0.176 ms per pass against 0.132 with two.)
+static inline hipStream_t lane_stream(ampli_ctx *ctx, const int k) { return ctx->lanes[k].stream; }
 
 int ampli_ranges_join_internal(ampli_ctx *ctx)
 {
     if (!ctx->ranges_open) return AMPLI_OK;
     ctx->ranges_open = false;
-    for (int k = 1; k < ctx->n_ranges; ++k) {
+    for (int k = 0; k < ctx->n_ranges; ++k) {
         HIP_TRY(ctx, hipEventRecord(ctx->lanes[k].done, ctx->lanes[k].stream));
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[k].done, 0));
     }
@@ -183,7 +188,7 @@ static int ranges_fork(ampli_ctx *ctx, const long long P)
     if (ctx->ranges_open && ctx->ranges_P == P) return AMPLI_OK;
     { int rc = ampli_ranges_join_internal(ctx); if (rc) return rc; }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    for (int k = 1; k < ctx->n_ranges; ++k) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[k].stream, ctx->ev_fork, 0));
+    for (int k = 0; k < ctx->n_ranges; ++k) HIP_TRY(ctx, hipStreamWaitEvent(ctx->lanes[k].stream, ctx->ev_fork, 0));
     ctx->ranges_open = true;
     ctx->ranges_P = P;
     return AMPLI_OK;
@@ -198,6 +203,48 @@ static bool ranges_apply(ampli_ctx *ctx, const long long P)
     return true;
 }
 
+// Two streams overlap only if HIP has put them on different hardware queues -- it deals streams to a few queues (four by default) by
+// rules of its own, and two ranges on one queue simply run one after the other (measured: three ranges of which two shared a queue,
+// 0.18 ms per pass against 0.155 on one stream).  ampli_set_ranges therefore CHECKS: a short sleeping kernel on both streams at once
+// takes its own time if they overlap and twice that if they do not; a stream that shares a queue with an earlier range's is
+// replaced by a new one (a few tries).  ~0.2 ms per pair, once.
+__global__ void lane_probe_kernel(const int iters)
+{
+    for (int i = 0; i < iters; ++i) __builtin_amdgcn_s_sleep(127); // 127 x 64 cycles: ~3.4 us per turn at 2.4 GHz; bounded
+}
+
+static int lanes_overlap(ampli_ctx *ctx, hipStream_t a, hipStream_t b, bool *overlap)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    HIP_TRY(ctx, hipEventCreate(&e2));
+    float alone = 0, both = 0;
+    for (int pass = 0; pass < 2; ++pass) { // the first pass warms the kernel's code object and both queues
+        HIP_TRY(ctx, hipEventRecord(e0, a));
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, a, 24);
+        HIP_TRY(ctx, hipEventRecord(e1, a));
+        HIP_TRY(ctx, hipStreamSynchronize(a));
+        HIP_TRY(ctx, hipEventElapsedTime(&alone, e0, e1));
+        HIP_TRY(ctx, hipEventRecord(e0, a));
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, a, 24);
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, b, 24);
+        HIP_TRY(ctx, hipEventRecord(e1, a));
+        HIP_TRY(ctx, hipEventRecord(e2, b));
+        HIP_TRY(ctx, hipStreamSynchronize(a));
+        HIP_TRY(ctx, hipStreamSynchronize(b));
+        float ta = 0, tb = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ta, e0, e1));
+        HIP_TRY(ctx, hipEventElapsedTime(&tb, e0, e2));
+        both = ta > tb ? ta : tb;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    *overlap = both < 1.6f * alone; // one after the other: ~2 x
+    return check_launch(ctx, "lane_probe_kernel");
+}
+
+extern "C" int ampli_ranges_concurrent(const ampli_ctx *ctx) { return ctx ? ctx->ranges_verified : AMPLI_E_INVALID; }
+
 extern "C" int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges)
 {
     if (!ctx) return AMPLI_E_INVALID;
@@ -205,10 +252,28 @@ extern "C" int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     { int rc = ampli_ranges_join_internal(ctx); if (rc) return rc; }
     if (n_ranges > 1 && !ctx->ev_fork) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    for (int k = 1; k < n_ranges; ++k) {
+    ctx->ranges_verified = n_ranges > 1 ? 1 : 0;
+    for (int k = 0; k < n_ranges && n_ranges > 1; ++k) {
         AmpliLane &l = ctx->lanes[k];
-        if (!l.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         if (!l.done) HIP_TRY(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        if (l.stream && l.verified) continue; // kept from an earlier call: already known to overlap with the lanes before it
+        hipStream_t spare[8];
+        int n_spare = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
+            if (!l.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+            ok = true;
+            for (int j = 0; j < k && ok; ++j) {
+                int rc = lanes_overlap(ctx, ctx->lanes[j].stream, l.stream, &ok);
+                if (rc) return rc;
+            }
+            // a stream that shares a queue with an earlier range's is kept alive until the search ends: destroyed at once, the next one
+            // created would take its place on the same queue
+            if (!ok) { spare[n_spare++] = l.stream; l.stream = nullptr; }
+        }
+        if (!ok) { l.stream = spare[--n_spare]; ctx->ranges_verified = 0; } // no luck: the ranges still give the right results, two of them in turn
+        for (int i = 0; i < n_spare; ++i) (void)hipStreamDestroy(spare[i]);
+        l.verified = ok;
     }
     ctx->n_ranges = n_ranges;
     return AMPLI_OK;

@@ -792,7 +792,7 @@ def main():
         r_red = [sum(ctx.elapsed_ms(evr[i][k][0], evr[i][k][1]) for i in ev_steps) / len(ev_steps) for k in range(n_ranges)]
         r_call = [sum(ctx.elapsed_ms(evr[i][k][1], evr[i][k][2]) for i in ev_steps) / len(ev_steps) for k in range(n_ranges)]
         t_red, t_call_main = sum(r_red) / n_ranges, sum(r_call) / n_ranges  # mean launch (each launch = 1 / n of the panel)
-        ranges_block = {"n": n_ranges, "positions": [cuts[k + 1] - cuts[k] for k in range(n_ranges)], "error_reduce_ms": r_red, "poisson_call_ms": r_call,
+        ranges_block = {"n": n_ranges, "streams_seen_to_overlap": ctx.ranges_concurrent(), "positions": [cuts[k + 1] - cuts[k] for k in range(n_ranges)], "error_reduce_ms": r_red, "poisson_call_ms": r_call,
                         "note": "ampli_set_ranges: every range's error_estimate + poisson_call on a stream of its own inside the library; durations by "
                                 "events on the range's stream (ampli_range_event_record), i.e. of launches that share the chip with the other ranges'"}
         # the outputs the ranges left behind (last pass of the timed region), to be compared with the one-stream pass's below

@@ -492,8 +492,8 @@ int ampli_last_reduce_kernel(const ampli_ctx *ctx);
  * Position ranges on concurrent streams (round 5).  A resident panel is rarely a whole number of rounds of workgroups (config 3:
  * 1563 tiles of 64 positions on 1280 resident workgroups of error_reduce), and a launch's partly filled last round runs at a
  * fraction of the chip.  With n_ranges > 1 (at most 4) ampli_error_estimate / ampli_error_reduce_records and ampli_poisson_call /
- * _records (prefilter mode) cut the panel into n tile-aligned ranges of positions: range 0 runs on the context's stream, range k on
- * a stream the context owns, each range's poisson_call behind its own error_estimate (a position's thresholds are all a
+ * _records (prefilter mode) cut the panel into n tile-aligned ranges of positions, each on a stream the context
+ * owns (the context's own stream only forks into them and joins them), each range's poisson_call behind its own error_estimate (a position's thresholds are all a
  * record of that position needs).  Over BACK-TO-BACK passes on independent batches one range's poisson_call and another's
  * error_reduce then fill each other's thin rounds (config 3: 0.146 -> 0.12-0.13 ms per pass); a single pass gains nothing -- the
  * join at its end costs what the overlap inside it saves -- so the command lines do not use it.  Outputs are the same arrays,
@@ -508,6 +508,10 @@ int ampli_last_reduce_kernel(const ampli_ctx *ctx);
  */
 int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges);
 int ampli_ranges_join(ampli_ctx *ctx);
+/* 1 when ampli_set_ranges saw every pair of the ranges' streams run concurrently; 0 when it could not find streams on different
+ * hardware queues (HIP deals streams to a few queues by rules of its own: ampli_set_ranges probes each new stream against the earlier
+ * ranges' with a short sleeping kernel and replaces one that shares a queue) -- results are the same either way, the overlap is not. */
+int ampli_ranges_concurrent(const ampli_ctx *ctx);
 /* An event (ampli_event_create) on range `range`'s stream WITHOUT closing the section: events recorded before and after a call
  * bracket that range's share of it -- the kernels' durations under the overlap the ranges exist for.  (ampli_event_record is an
  * ordinary call: it closes the section first and records on the context's stream.) */
