@@ -345,6 +345,7 @@ def test_position_ranges_inside_the_library(ctx16, P, S, T, n):
         wres = ctx16.poisson_call(td, P, whole.thr, rd, 100, capacity=1 << 16)
         wcalls = ctx16.read_calls(wres)
         ctx16.set_ranges(n)
+        assert ctx16.ranges_concurrent() in (True, False)  # whether every pair of the ranges' streams was seen to overlap: speed, not results
         fin = ctx16.error_estimate(nd, P, 0.002, 100)
         res = ctx16.poisson_call(td, P, fin.thr, rd, 100, capacity=1 << 16)
         ev = [[ctx16.event() for _ in range(3)] for _ in range(n)]
