@@ -215,10 +215,12 @@ __global__ void lane_probe_kernel(const int iters)
 
 static int lanes_overlap(ampli_ctx *ctx, hipStream_t a, hipStream_t b, bool *overlap)
 {
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
-    HIP_TRY(ctx, hipEventCreate(&e2));
+    struct Events { // destroyed on every path out
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (hipEvent_t &x : ev.e) HIP_TRY(ctx, hipEventCreate(&x));
+    hipEvent_t e0 = ev.e[0], e1 = ev.e[1], e2 = ev.e[2];
     float alone = 0, both = 0;
     for (int pass = 0; pass < 2; ++pass) { // the first pass warms the kernel's code object and both queues
         HIP_TRY(ctx, hipEventRecord(e0, a));
@@ -238,7 +240,6 @@ static int lanes_overlap(ampli_ctx *ctx, hipStream_t a, hipStream_t b, bool *ove
         HIP_TRY(ctx, hipEventElapsedTime(&tb, e0, e2));
         both = ta > tb ? ta : tb;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
     *overlap = both < 1.6f * alone; // one after the other: ~2 x
     return check_launch(ctx, "lane_probe_kernel");
 }
@@ -257,8 +258,11 @@ extern "C" int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges)
         AmpliLane &l = ctx->lanes[k];
         if (!l.done) HIP_TRY(ctx, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
         if (l.stream && l.verified) continue; // kept from an earlier call: already known to overlap with the lanes before it
-        hipStream_t spare[8];
-        int n_spare = 0;
+        struct Spare { // streams set aside during the search, destroyed on every path out
+            hipStream_t s[8];
+            int n = 0;
+            ~Spare() { for (int i = 0; i < n; ++i) (void)hipStreamDestroy(s[i]); }
+        } spare;
         bool ok = false;
         for (int attempt = 0; attempt < 8 && !ok; ++attempt) {
             if (!l.stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
@@ -269,10 +273,9 @@ extern "C" int ampli_set_ranges(ampli_ctx *ctx, int32_t n_ranges)
             }
             // a stream that shares a queue with an earlier range's is kept alive until the search ends: destroyed at once, the next one
             // created would take its place on the same queue
-            if (!ok) { spare[n_spare++] = l.stream; l.stream = nullptr; }
+            if (!ok) { spare.s[spare.n++] = l.stream; l.stream = nullptr; }
         }
-        if (!ok) { l.stream = spare[--n_spare]; ctx->ranges_verified = 0; } // no luck: the ranges still give the right results, two of them in turn
-        for (int i = 0; i < n_spare; ++i) (void)hipStreamDestroy(spare[i]);
+        if (!ok) { l.stream = spare.s[--spare.n]; ctx->ranges_verified = 0; } // no luck: the ranges still give the right results, two of them in turn
         l.verified = ok;
     }
     ctx->n_ranges = n_ranges;
