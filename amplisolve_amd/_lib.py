@@ -114,7 +114,6 @@ HIP_SYMBOLS = {
     "ampli_ranges_concurrent": (C.c_int, [vp]),
     "ampli_range_event_record": (C.c_int, [vp, i32, vp]),
     "ampli_set_reduce_compact": (C.c_int, [vp, i32]),
-    "ampli_set_reduce_fold": (C.c_int, [vp, i32]),
     "ampli_last_reduce_kernel": (C.c_int, [vp]),
     "ampli_set_tuning": (C.c_int, [vp, i32, i32, i32]),
     "ampli_ctx_flags": (C.c_int, [vp, C.POINTER(i32), i32]),

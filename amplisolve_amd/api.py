@@ -218,10 +218,6 @@ class Context:
         """True / False; 2 = the compact-state kernel for uint16 records only (A/B runs of its 24-bit form)"""
         self._check(self.lib.ampli_set_reduce_compact(self.h, 2 if on == 2 else int(bool(on))))
 
-    def set_reduce_fold(self, on: bool):
-        """fold a thin last round of tiles into the last whole round's workgroups (compact kernels; default on); same results"""
-        self._check(self.lib.ampli_set_reduce_fold(self.h, int(bool(on))))
-
     def set_slice_format(self, slim: bool):
         """sums of the sliced exchange as 14 packed planes (slim) or 21 plain ones (ampli_set_slice_format)"""
         self._check(self.lib.ampli_set_slice_format(self.h, 1 if slim else 0))

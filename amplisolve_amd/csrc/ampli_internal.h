@@ -38,7 +38,6 @@ struct ampli_ctx {
     int reduce_general = 0; // 1 = literal kernel (any depth), 0 = fast kernel (depths < 2^22)
     int last_reduce_kernel = -1; // 0 general, 1 compact uint16, 2 compact 24-bit (ampli_last_reduce_kernel)
     int reduce_compact_u16_only = 0; // ampli_set_reduce_compact(ctx, 2)
-    int reduce_fold = 1;    // the compact kernels fold a thin last round of tiles into the last whole round's workgroups (ampli_set_reduce_fold)
     int reduce_compact = 1; // 1 = error_reduce_u16_kernel (compact state, five waves per SIMD) where its shape applies (ampli_set_reduce_compact)
     int grp_size = 1, grp_index = 0; // sliced exchange buffers hold grp_size batches per slice chunk; calls address batch grp_index
     int slice_fmt = 0;               // AMPLI_SLICE_WIDE / AMPLI_SLICE_SLIM: what the sums of the sliced exchange look like (ampli_set_slice_format)

@@ -459,13 +459,6 @@ extern "C" int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on)
     return AMPLI_OK;
 }
 
-extern "C" int ampli_set_reduce_fold(ampli_ctx *ctx, int32_t on)
-{
-    if (!ctx) return AMPLI_E_INVALID;
-    ctx->reduce_fold = on ? 1 : 0;
-    return AMPLI_OK;
-}
-
 extern "C" int ampli_last_reduce_kernel(const ampli_ctx *ctx)
 {
     return ctx && ctx->last_reduce_kernel >= 0 ? ctx->last_reduce_kernel : AMPLI_E_INVALID;
@@ -1470,9 +1463,22 @@ __device__ __forceinline__ void part16_store(const AccPtrs &t, const long long P
 // below FAST_COUNT_LIMIT = 2^22 (checked per record) and a lane takes at most COMPACT_MAX_REC_U24 = 1023 records: a strand depth sum
 // is then < 2^22 x 1023 < 2^32 (kept and widened as unsigned), a sum of X < 0.05 x 2^22 x 1023 < 2^28, a count < 2^16.
 constexpr int COMPACT_MAX_REC_U24 = 1023;
-
-__device__ __forceinline__ void fast16_init(Fast16 &f)
+template <int LAY, bool DUP, bool TAB>
+__device__ __forceinline__ void compact_reduce_body(Red16Shared &sh, const RecView &rv, const long long P, const long long p_lo, const long long p_hi,
+                                                    const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
+                                                    const float C, const int cov, int *__restrict__ flags, const AccPtrs &tab,
+                                                    const FinOut &fin)
 {
+    constexpr int RB = rec_bytes_of<LAY>();
+    constexpr bool DC = LAY != AMPLI_RECORDS_U16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long p_raw = p_lo + (long long)blockIdx.x * 64 + lane;
+    const bool valid = p_raw < p_hi;
+    const long long p = valid ? p_raw : p_hi - 1; // clamp: out-of-range lanes re-read the last position, never store
+    const int s0 = min(S, wave * chunk_len);
+    const int s1 = min(S, s0 + chunk_len);
+    Fast16 f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         f.sx[0][nt] = f.sx[1][nt] = 0; f.sd[0][nt] = f.sd[1][nt] = 0; f.sp[0][nt] = f.sp[1][nt] = 0.0;
@@ -1480,11 +1486,44 @@ __device__ __forceinline__ void fast16_init(Fast16 &f)
     }
     f.cnt01 = f.cnt23 = 0u;
     f.nrec_bad = 0u;
-}
-
-// a lane's row-loop state as the summary the chunks are combined in
-__device__ __forceinline__ void fast16_to_part(const Fast16 &f, const int lane, Part16 &a)
-{
+    const size_t row_step = (size_t)rv.row_stride * RB;
+    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;
+    if (DUP) { // a tile with a position listed more than once is left to error_reduce_kernel (launched over the list of such tiles)
+        if (__any(dup_off[p + 1] != dup_off[p])) return; // the four waves of a workgroup see the same tile: all leave, before any barrier
+    }
+    // Three named register sets in rotation: rows s + 1 and s + 2 are in flight while row s is consumed (s_waitcnt vmcnt(2)).
+    // (Written as one row per trip with a "next" record, hipcc copies the freshly loaded record into the loop-carried registers
+    // at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none; that form ran
+    // at 166 us on config 3 against the general kernel's 124; two sets, one row in flight: 107; three: 102.)  Past the end of
+    // the chunk the loads stay on its last row (cache hits) and the rows are not visited.
+    RawRec<LAY> ra = rec_load_at<LAY>(q), rb, rc;
+    if (s0 + 1 < s1) q += row_step;
+    rb = rec_load_at<LAY>(q);
+    for (int s = s0; s < s1; s += 3) {
+        if (s + 2 < s1) q += row_step;
+        rc = rec_load_at<LAY>(q);
+        {
+            int4 c0, c1;
+            rec_decode<LAY>(ra, c0, c1);
+            if (s < s1) visit16<DC>(f, c0, c1, C, cov);
+        }
+        if (s + 3 < s1) q += row_step;
+        ra = rec_load_at<LAY>(q);
+        {
+            int4 c0, c1;
+            rec_decode<LAY>(rb, c0, c1);
+            if (s + 1 < s1) visit16<DC>(f, c0, c1, C, cov);
+        }
+        if (s + 4 < s1) q += row_step;
+        rb = rec_load_at<LAY>(q);
+        {
+            int4 c0, c1;
+            rec_decode<LAY>(rc, c0, c1);
+            if (s + 2 < s1) visit16<DC>(f, c0, c1, C, cov);
+        }
+    }
+    if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)(DC ? COMPACT_MAX_REC_U24 : FAST_MAX_RECORDS) || (DC && (f.nrec_bad >> 31))) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
+    Part16 a;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -1501,14 +1540,7 @@ __device__ __forceinline__ void fast16_to_part(const Fast16 &f, const int lane, 
     a.cnt[0] = (int)(f.cnt01 & 0xFFFFu); a.cnt[1] = (int)(f.cnt01 >> 16);
     a.cnt[2] = (int)(f.cnt23 & 0xFFFFu); a.cnt[3] = (int)(f.cnt23 >> 16);
     a.nrec = (int)(f.nrec_bad & 0x7FFFFFFFu);
-}
-
-// the four waves' summaries in sample order (a tree over adjacent chunks: waves 1, 3 hand over to 0, 2; then 2 to 0), then wave 0's
-// epilogue for the lanes that own a position: carry-in / table store / slice-major store / finalize
-template <bool TAB>
-__device__ __forceinline__ void compact_tree_and_epilogue(Red16Shared &sh, Part16 &a, const int wave, const int lane, const bool owns, const long long P,
-                                                          const long long p_raw, const float C, const int cov, const AccPtrs &tab, const FinOut &fin)
-{
+    // the four chunks in sample order, a tree over adjacent chunks: waves 1, 3 hand over to 0, 2; then 2 to 0
     if (wave & 1) part16_put(sh, wave >> 1, lane, a);
     __syncthreads();
     if (!(wave & 1)) part16_merge(a, sh, wave >> 1, lane);
@@ -1517,7 +1549,7 @@ __device__ __forceinline__ void compact_tree_and_epilogue(Red16Shared &sh, Part1
     __syncthreads();
     if (wave == 0) {
         part16_merge(a, sh, 0, lane);
-        if (owns) {
+        if (valid) {
             unsigned had = 0;
             if (TAB && fin.accumulate) had = part16_carry_in(a, tab, P, p_raw); // earlier chunks of the cohort (+) this one
             if (TAB && tab.snt) part16_store(tab, P, p_raw, a, had);
@@ -1534,171 +1566,24 @@ __device__ __forceinline__ void compact_tree_and_epilogue(Red16Shared &sh, Part1
     }
 }
 
-// L = L (+) (the summary `off` lanes further on), L covering the earlier samples: part16_merge across the lane groups of a wave
-__device__ __forceinline__ void part16_merge_shfl(Part16 &L, const int off, const bool take)
-{
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const double rs = __shfl_down(L.snt[st][nt], off);
-            const long long rd = __shfl_down(L.srd[st][nt], off);
-            if (take) { L.snt[st][nt] += rs; L.srd[st][nt] += rd; }
-        }
-        const int rc = __shfl_down(L.cnt[nt], off), rn = __shfl_down(L.gm_n[nt], off);
-        const float rf = __shfl_down(L.gm_first_af[nt], off), rr = __shfl_down(L.gm_rest[nt], off);
-        if (take) {
-            L.cnt[nt] += rc;
-            if (rn != 0) {
-                if (L.gm_n[nt] == 0) {
-                    L.gm_first_af[nt] = rf; L.gm_rest[nt] = rr;
-                } else {
-                    float m = L.gm_rest[nt];
-                    if (m <= rf) m = rf;
-                    if (m <= rr) m = rr;
-                    L.gm_rest[nt] = m;
-                }
-                L.gm_n[nt] += rn;
-            }
-        }
-    }
-    const int rnrec = __shfl_down(L.nrec, off);
-    if (take) L.nrec += rnrec;
-}
-
-// FOLD (round 5): the launch is n_main whole tiles, a whole number of rounds of resident workgroups, and the panel's remaining
-// positions -- what would be a thin last round (config 3: 283 tiles behind 1280) -- are FOLDED into the last round's workgroups:
-// workgroup fold_first + o takes the 16 positions [rem_lo + 16 o, ...) on top of its tile, its waves cut into four lane groups of 16
-// positions x 4 sample sub-chunks (16 rows per lane instead of 64: a quarter of a tile's time for a quarter of a tile's positions, with
-// every lane busy), the groups combined in sample order by shuffles, then the waves through the same tree.  One round of workgroups
-// of 1.25 x the rows instead of 1.22 rounds: config 3 through the reduce in ~88 us instead of ~100 (tools/fold_probe.py).
-template <int LAY, bool DUP, bool TAB, bool FOLD>
-__device__ __forceinline__ void compact_reduce_body(Red16Shared &sh, const RecView &rv, const long long P, const long long p_lo, const long long p_hi,
-                                                    const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
-                                                    const float C, const int cov, int *__restrict__ flags, const AccPtrs &tab,
-                                                    const FinOut &fin, const unsigned fold_first, const long long rem_lo)
-{
-    constexpr int RB = rec_bytes_of<LAY>();
-    constexpr bool DC = LAY != AMPLI_RECORDS_U16;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long p_raw = p_lo + (long long)blockIdx.x * 64 + lane;
-    const bool valid = p_raw < p_hi;
-    const long long p = valid ? p_raw : p_hi - 1; // clamp: out-of-range lanes re-read the last position, never store
-    const int s0 = min(S, wave * chunk_len);
-    const int s1 = min(S, s0 + chunk_len);
-    Fast16 f;
-    fast16_init(f);
-    const size_t row_step = (size_t)rv.row_stride * RB;
-    const char *__restrict__ q = rv.base + ((size_t)min(s0, S - 1) * (size_t)rv.row_stride + (size_t)p) * RB;
-    if (DUP) { // a tile with a position listed more than once is left to error_reduce_kernel (launched over the list of such tiles)
-        if (__any(dup_off[p + 1] != dup_off[p])) return; // the four waves of a workgroup see the same tile: all leave, before any barrier
-    }
-    // Three named register sets in rotation: rows s + 1 and s + 2 are in flight while row s is consumed (s_waitcnt vmcnt(2)).
-    // (Written as one row per trip with a "next" record, hipcc copies the freshly loaded record into the loop-carried registers
-    // at the latch and waits for it there -- s_waitcnt vmcnt(0) right behind the load -- so the prefetch is none; that form ran
-    // at 166 us on config 3 against the general kernel's 124; two sets, one row in flight: 107; three: 102.)  Past the end of
-    // the chunk the loads stay on its last row (cache hits) and the rows are not visited.
-    {
-        RawRec<LAY> ra = rec_load_at<LAY>(q), rb, rc;
-        if (s0 + 1 < s1) q += row_step;
-        rb = rec_load_at<LAY>(q);
-        for (int s = s0; s < s1; s += 3) {
-            if (s + 2 < s1) q += row_step;
-            rc = rec_load_at<LAY>(q);
-            {
-                int4 c0, c1;
-                rec_decode<LAY>(ra, c0, c1);
-                if (s < s1) visit16<DC>(f, c0, c1, C, cov);
-            }
-            if (s + 3 < s1) q += row_step;
-            ra = rec_load_at<LAY>(q);
-            {
-                int4 c0, c1;
-                rec_decode<LAY>(rb, c0, c1);
-                if (s + 1 < s1) visit16<DC>(f, c0, c1, C, cov);
-            }
-            if (s + 4 < s1) q += row_step;
-            rb = rec_load_at<LAY>(q);
-            {
-                int4 c0, c1;
-                rec_decode<LAY>(rc, c0, c1);
-                if (s + 2 < s1) visit16<DC>(f, c0, c1, C, cov);
-            }
-        }
-    }
-    if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)(DC ? COMPACT_MAX_REC_U24 : FAST_MAX_RECORDS) || (DC && (f.nrec_bad >> 31))) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
-    Part16 a;
-    fast16_to_part(f, lane, a);
-    compact_tree_and_epilogue<TAB>(sh, a, wave, lane, valid, P, p_raw, C, cov, tab, fin);
-    if (!FOLD || blockIdx.x < fold_first) return; // block-uniform
-    // ---- the folded remainder: 16 positions x (4 waves x 4 lane groups) sample sub-chunks ----
-    const int grp = lane >> 4;
-    const long long p2_raw = rem_lo + (long long)(blockIdx.x - fold_first) * 16 + (lane & 15);
-    const bool valid2 = p2_raw < p_hi;
-    const long long p2 = valid2 ? p2_raw : p_hi - 1;
-    const int len16 = (S + 15) / 16;                 // rows per lane group; wave-uniform trip count below
-    const int t0 = min(S, (wave * 4 + grp) * len16); // this lane's sub-chunk [t0, t1): chunk order = sample order
-    const int my_n = min(S, t0 + len16) - t0;
-    fast16_init(f);
-    q = rv.base + ((size_t)min(t0, S - 1) * (size_t)rv.row_stride + (size_t)p2) * RB;
-    {
-        RawRec<LAY> ra = rec_load_at<LAY>(q), rb, rc;
-        if (1 < my_n) q += row_step;
-        rb = rec_load_at<LAY>(q);
-        for (int i = 0; i < len16; i += 3) {
-            if (i + 2 < my_n) q += row_step;
-            rc = rec_load_at<LAY>(q);
-            {
-                int4 c0, c1;
-                rec_decode<LAY>(ra, c0, c1);
-                if (i >= my_n) c0.x = AMPLI_ABSENT; // past this lane's sub-chunk: an absent record changes nothing
-                visit16<DC>(f, c0, c1, C, cov);
-            }
-            if (i + 3 < my_n) q += row_step;
-            ra = rec_load_at<LAY>(q);
-            if (i + 1 < len16) {
-                int4 c0, c1;
-                rec_decode<LAY>(rb, c0, c1);
-                if (i + 1 >= my_n) c0.x = AMPLI_ABSENT;
-                visit16<DC>(f, c0, c1, C, cov);
-            }
-            if (i + 4 < my_n) q += row_step;
-            rb = rec_load_at<LAY>(q);
-            if (i + 2 < len16) {
-                int4 c0, c1;
-                rec_decode<LAY>(rc, c0, c1);
-                if (i + 2 >= my_n) c0.x = AMPLI_ABSENT;
-                visit16<DC>(f, c0, c1, C, cov);
-            }
-        }
-    }
-    if ((f.nrec_bad & 0x7FFFFFFFu) > (unsigned)(DC ? COMPACT_MAX_REC_U24 : FAST_MAX_RECORDS) || (DC && (f.nrec_bad >> 31))) atomicOr(flags, AMPLI_FLAG_RERUN_GENERAL);
-    fast16_to_part(f, lane, a);
-    part16_merge_shfl(a, 16, (grp & 1) == 0); // groups 0 <- 1, 2 <- 3
-    part16_merge_shfl(a, 32, grp == 0);       // group 0 <- 2: lanes 0-15 hold the wave's 16 positions
-    __syncthreads();                          // wave 0 is done with the first tree's last slot
-    compact_tree_and_epilogue<TAB>(sh, a, wave, lane, valid2 && grp == 0, P, p2_raw, C, cov, tab, fin);
-}
-
-template <bool DUP, bool TAB, bool FOLD>
+template <bool DUP, bool TAB>
 __global__ __launch_bounds__(256, 5) void error_reduce_u16_kernel(const RecView rv, const long long P, const long long p_lo, const long long p_hi,
                                                                   const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
                                                                   const float C, const int cov, int *__restrict__ flags, const AccPtrs tab,
-                                                                  const FinOut fin, const unsigned fold_first, const long long rem_lo)
+                                                                  const FinOut fin)
 {
     __shared__ Red16Shared sh;
-    compact_reduce_body<AMPLI_RECORDS_U16, DUP, TAB, FOLD>(sh, rv, P, p_lo, p_hi, dup_off, S, chunk_len, C, cov, flags, tab, fin, fold_first, rem_lo);
+    compact_reduce_body<AMPLI_RECORDS_U16, DUP, TAB>(sh, rv, P, p_lo, p_hi, dup_off, S, chunk_len, C, cov, flags, tab, fin);
 }
 
-template <bool DUP, bool TAB, bool FOLD>
+template <bool DUP, bool TAB>
 __global__ __launch_bounds__(256, 5) void error_reduce_u24_kernel(const RecView rv, const long long P, const long long p_lo, const long long p_hi,
                                                                   const unsigned *__restrict__ dup_off, const int S, const int chunk_len,
                                                                   const float C, const int cov, int *__restrict__ flags, const AccPtrs tab,
-                                                                  const FinOut fin, const unsigned fold_first, const long long rem_lo)
+                                                                  const FinOut fin)
 {
     __shared__ Red16Shared sh;
-    compact_reduce_body<AMPLI_RECORDS_U24, DUP, TAB, FOLD>(sh, rv, P, p_lo, p_hi, dup_off, S, chunk_len, C, cov, flags, tab, fin, fold_first, rem_lo);
+    compact_reduce_body<AMPLI_RECORDS_U24, DUP, TAB>(sh, rv, P, p_lo, p_hi, dup_off, S, chunk_len, C, cov, flags, tab, fin);
 }
 
 // dst = parts[0] (+) parts[1] (+) ... in order; parts are tables at base + i*stride
@@ -2757,28 +2642,14 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
         AccPtrs tab = {};
         if (d_acc) tab = to_ptrs(d_acc);
         const int clen = (S + RED_WAVES - 1) / RED_WAVES;
-#define AMPLI_LAUNCH_CK(KERNEL, DUPV, TABV, FOLDV, ST, LO, HI, NBLK, FF, RLO)                                                                       \
-    hipLaunchKernelGGL((KERNEL<DUPV, TABV, FOLDV>), dim3((unsigned)(NBLK)), dim3(256), 0, ST, co.rv, (long long)P,                                  \
-                       (long long)(LO), (long long)(HI), d_dup_off, (int)S, clen, C, (int)cov, ctx->d_flags, tab, fin, (unsigned)(FF), (long long)(RLO))
-#define AMPLI_LAUNCH_CL(DUPV, TABV, FOLDV, ST, LO, HI, NBLK, FF, RLO)                                                                              \
+#define AMPLI_LAUNCH_CK(KERNEL, DUPV, TABV, ST, LO, HI)                                                                                            \
+    hipLaunchKernelGGL((KERNEL<DUPV, TABV>), dim3((unsigned)(((HI) - (LO) + 63) / 64)), dim3(256), 0, ST, co.rv, (long long)P,                      \
+                       (long long)(LO), (long long)(HI), d_dup_off, (int)S, clen, C, (int)cov, ctx->d_flags, tab, fin)
+#define AMPLI_LAUNCH_U16(DUPV, TABV, ST, LO, HI)                                                                                                   \
     do {                                                                                                                                           \
-        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_CK(error_reduce_u24_kernel, DUPV, TABV, FOLDV, ST, LO, HI, NBLK, FF, RLO);                \
-        else AMPLI_LAUNCH_CK(error_reduce_u16_kernel, DUPV, TABV, FOLDV, ST, LO, HI, NBLK, FF, RLO);                                               \
+        if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_CK(error_reduce_u24_kernel, DUPV, TABV, ST, LO, HI);                                      \
+        else AMPLI_LAUNCH_CK(error_reduce_u16_kernel, DUPV, TABV, ST, LO, HI);                                                                     \
     } while (0)
-#define AMPLI_LAUNCH_U16(DUPV, TABV, ST, LO, HI) AMPLI_LAUNCH_CL(DUPV, TABV, false, ST, LO, HI, ((HI) - (LO) + 63) / 64, 0, 0)
-        // positions [lo, hi) on `st`, with `share` of the chip's resident workgroups to itself (1, or the number of concurrent ranges): a
-        // thin last round -- at most a quarter of a round of tiles behind whole rounds -- is folded into the last whole round's workgroups
-        // (compact_reduce_body, FOLD); every other shape is one workgroup per tile
-        auto launch_compact = [&](hipStream_t st, const long long lo, const long long hi, const int share) {
-            const long long tiles_k = (hi - lo + 63) / 64, Wk = std::max<long long>(1, (long long)ctx->n_cu * 5 / share), rem = tiles_k % Wk;
-            if (ctx->reduce_fold && tiles_k > Wk && rem != 0 && rem * 4 <= Wk) {
-                const long long n_main = tiles_k - rem;
-                if (d_acc) AMPLI_LAUNCH_CL(false, true, true, st, lo, hi, n_main, n_main - Wk, lo + 64 * n_main);
-                else AMPLI_LAUNCH_CL(false, false, true, st, lo, hi, n_main, n_main - Wk, lo + 64 * n_main);
-            } else {
-                if (d_acc) AMPLI_LAUNCH_U16(false, true, st, lo, hi); else AMPLI_LAUNCH_U16(false, false, st, lo, hi);
-            }
-        };
         if (E > 0) {
             // the tiles with a position listed more than once go to the general kernel (at most one such tile per extra slot)
             hipStream_t st = main_stream(ctx);
@@ -2804,12 +2675,15 @@ static int error_reduce_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, int
             if (rcf) return rcf;
             long long cut[AMPLI_MAX_RANGES + 1];
             range_cuts(P, ctx->n_ranges, cut);
-            for (int k = 0; k < ctx->n_ranges; ++k) launch_compact(lane_stream(ctx, k), cut[k], cut[k + 1], ctx->n_ranges);
+            for (int k = 0; k < ctx->n_ranges; ++k) {
+                hipStream_t st = lane_stream(ctx, k);
+                if (d_acc) AMPLI_LAUNCH_U16(false, true, st, cut[k], cut[k + 1]); else AMPLI_LAUNCH_U16(false, false, st, cut[k], cut[k + 1]);
+            }
             return check_launch(ctx, "error_reduce_u16_kernel");
         }
-        launch_compact(main_stream(ctx), 0, P, 1);
+        hipStream_t st = main_stream(ctx);
+        if (d_acc) AMPLI_LAUNCH_U16(false, true, st, 0, P); else AMPLI_LAUNCH_U16(false, false, st, 0, P);
 #undef AMPLI_LAUNCH_U16
-#undef AMPLI_LAUNCH_CL
 #undef AMPLI_LAUNCH_CK
         return check_launch(ctx, "error_reduce_u16_kernel");
     }

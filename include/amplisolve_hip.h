@@ -484,11 +484,6 @@ int ampli_set_tuning(ampli_ctx *ctx, int32_t reduce_sample_splits, int32_t reduc
  * (AMPLI_REDUCE_SUMMARY).  Positions listed more than once (E > 0) are served: their tiles go to the general kernel over a list.
  * Every other launch takes the general kernel.  Same results, bit for bit.  on = 2: the uint16 form only (A/B runs). */
 int ampli_set_reduce_compact(ampli_ctx *ctx, int32_t on);
-/* The compact kernels fold a thin last round of workgroups into the round before it (on != 0, the default): when a launch is whole
- * rounds of resident workgroups (five per CU) plus at most a quarter of a round of tiles, the workgroups of the last whole round each
- * take 16 of the remaining positions on top of their tile, their waves cut into four lane groups over sample sub-chunks, instead of
- * a second, thinly filled round (config 3: 1563 tiles = 1280 + 283).  Same results; off for A/B runs. */
-int ampli_set_reduce_fold(ampli_ctx *ctx, int32_t on);
 /* Which kernel the context's latest error_reduce launch was: 0 = error_reduce_kernel (general), 1 = error_reduce_u16_kernel,
  * 2 = error_reduce_u24_kernel (compact state); AMPLI_E_INVALID before the first launch.  For tests and the bench line, which name the kernel they measured. */
 int ampli_last_reduce_kernel(const ampli_ctx *ctx);

@@ -196,52 +196,3 @@ def test_last_chunk_of_a_shard_goes_slice_major(ctx, P, S, n, cuts, extras, slim
         ctx.set_tuning(0)
         ctx.set_slice_format(False)
         ctx.set_record_layout("i32")
-
-
-@pytest.mark.parametrize("lay", ["u16", "u24"])
-@pytest.mark.parametrize("P,S,ranges", [(81_921, 5, 1), (82_000, 16, 1), (100_000, 37, 1), (102_400, 9, 1), (102_401, 9, 1), (170_240, 7, 1),
-                                        (100_000, 21, 2), (90_000, 64, 1), (100_000, 3, 1)])
-def test_thin_last_round_folded_into_the_round_before(ctx, P, S, ranges, lay):
-    """The compact kernels fold a thin last round of workgroups (at most a quarter of a round of tiles behind whole rounds of five
-    workgroups per CU) into the last whole round: those workgroups take 16 of the remaining positions each, in four lane groups over
-    sample sub-chunks combined in sample order.  Panels around the window (one remainder position; exactly a quarter of a round; one
-    tile more than that: no fold; two whole rounds + a remainder; a launch cut into two position ranges, each folding its own): the
-    error table with the fold == without == the oracle's, also through the summary table of a streamed cohort."""
-    import torch
-
-    recs = synth_recs(P, S)
-    rng = np.random.default_rng(P + S)
-    # edge-case records on the remainder positions and on a stretch of the main tiles
-    tail = edge_case_recs(min(P, 24_000), S, rng)
-    recs[:, P - tail.shape[1]:] = np.where(tail == ABSENT, ABSENT, np.minimum(tail, 65534))
-    want = orc.error_finalize(orc.error_reduce(recs, P, 0.002, 100))
-    ctx.set_record_layout(lay)
-    ctx.set_tuning(1, groups=1)
-    try:
-        packed = _pack(ctx, recs, lay)
-        outs = []
-        for fold in (True, False):
-            ctx.set_reduce_fold(fold)
-            ctx.set_ranges(ranges)
-            got = ctx.error_estimate(packed, P, 0.002, 100)
-            assert ctx.flags() == 0 and ctx.last_reduce_kernel() == COMPACT[lay]
-            ctx.set_ranges(1)
-            assert_final_equal(got, want)
-            outs.append(got)
-        for k in ("rate", "thr", "code", "germ_present", "germ_val"):
-            assert torch.equal(getattr(outs[0], k).view(torch.uint8), getattr(outs[1], k).view(torch.uint8)), k
-        # two chunks through the table, folded
-        ctx.set_reduce_fold(True)
-        if S >= 2:
-            acc = ctx.new_acc(P)
-            v = packed.view(S, P, -1)
-            h = S // 2
-            ctx.error_reduce_records(ctx.records(v[:h].contiguous(), lay, h), P, acc, 0.002, 100, summary=True)
-            fin = ctx.error_reduce_records(ctx.records(v[h:].contiguous(), lay, S - h), P, acc, 0.002, 100, first_sample=h, accumulate=True, finalize=True, summary=True)
-            assert ctx.flags() == 0
-            assert_final_equal(fin, want)
-    finally:
-        ctx.set_reduce_fold(True)
-        ctx.set_ranges(1)
-        ctx.set_tuning(0)
-        ctx.set_record_layout("i32")
