@@ -46,3 +46,28 @@ for P, S in ((100_000, 256), (81_920, 320), (81_920, 256), (102_400, 256)):
         print(f"P {P} S {S} ({(P + 63) // 64} tiles, {P * S / 1e6:.1f} M records) {'alternating with poisson_call' if alt else 'back to back':30s}: "
               f"median {t[reps // 2] * 1e3:6.1f} us (min {t[0] * 1e3:6.1f}) = {b / t[reps // 2] / 1e9:5.2f} TB/s = {b / t[reps // 2] / 1e9 / 8:5.3f} of peak", flush=True)
     del n, fin
+
+# row stride: config 3's rows are 100 000 records = 1.6 MB apart; does a padded stride (ampli_records.row_stride) change the stream?
+P, S = 100_000, 256
+import numpy as np
+for stride in (100_000, 100_032, 100_096, 100_352, 101_376, 102_400, 100_000):
+    buf = torch.zeros((S, stride, 8), dtype=torch.int16, device="cuda")
+    dense = cohort(P, S).view(S, P, 8)
+    buf[:, :P] = dense
+    del dense
+    rec = ctx.records(buf, "u16", S, row_stride=stride)
+    fin = ctx.error_reduce_records(rec, P, None, finalize=True)
+    reps = 30
+    ev = [[ctx.event(), ctx.event()] for _ in range(reps)]
+    for i in range(reps + 3):
+        j = i - 3
+        if j >= 0:
+            ctx.record(ev[j][0])
+        ctx.error_reduce_records(rec, P, None, out=fin, finalize=True)
+        if j >= 0:
+            ctx.record(ev[j][1])
+        ctx.poisson_call(tum, PT, fin_t.thr, ref, 100, call_mask=res["call_mask"], capacity=res["capacity"], calls_buf=res["calls_buf"], n_calls=res["n_calls"])
+    torch.cuda.synchronize()
+    t = sorted(ctx.elapsed_ms(a, b) for a, b in ev)
+    print(f"row stride {stride} records ({stride * 16} B): error_estimate median {t[reps // 2] * 1e3:6.1f} us (min {t[0] * 1e3:6.1f}), alternating with poisson_call", flush=True)
+    del buf, rec, fin
