@@ -990,6 +990,27 @@ def main():
     # error_reduce against the SIZE of its launch: config 3 is 1563 tiles of 64 positions on 1280 (compact kernel) or 1024 resident
     # workgroups, i.e. one full round and a thin one; the same kernel on a panel of four whole rounds shows what the partly filled
     # round costs (tools/sweep_tiles.py).  Outside the timed region; N = 1 only.
+    # the practical ceiling beside the spec: a plain device-to-device copy of 1 GiB on this box, read + written bytes per second
+    copy_ceiling = None
+    if not multi and lanes is None:
+        try:
+            nbytes = 1 << 30
+            src_c, dst_c = torch.empty(nbytes, dtype=torch.uint8, device=ctx.device), torch.empty(nbytes, dtype=torch.uint8, device=ctx.device)
+            src_c.zero_()
+            dst_c.copy_(src_c)
+            torch.cuda.synchronize()
+            ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ca.record()
+            for _ in range(10):
+                dst_c.copy_(src_c)
+            cb.record()
+            torch.cuda.synchronize()
+            copy_ms = ca.elapsed_time(cb) / 10
+            copy_ceiling = {"GBs": 2 * nbytes / (copy_ms * 1e-3) / 1e9, "bytes_copied": nbytes, "ms": copy_ms,
+                            "note": "torch device-to-device copy of 1 GiB, read + written bytes, 10 copies back to back, after the timed region"}
+            del src_c, dst_c
+        except Exception as exc:  # noqa: BLE001
+            copy_ceiling = {"error": f"{type(exc).__name__}: {exc}"}
     whole_rounds = None
     if not multi and lanes is None and args.whole_rounds > 0:
         try:
@@ -1189,10 +1210,12 @@ def main():
                                        if args.records == "auto" else "--records given")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": dom_ms, "algorithmic_bytes": dom_bytes,
-                         "traffic_source": traffic_src, "measured": roof_measured},
+                         "traffic_source": traffic_src, "measured": roof_measured,
+                         "frac_of_copy_ceiling": (achieved / copy_ceiling["GBs"]) if copy_ceiling and copy_ceiling.get("GBs") else None},
             "roofline_overlapped": overlapped,
             # every kernel of a pass together: algorithmic bytes of the pass / time per pass over the timed region -- the figure that
             # is well defined when kernels of different ranges overlap
+            "copy_ceiling": copy_ceiling,
             "roofline_pass": {"bound": "hbm", "algorithmic_bytes": pass_red_bytes + pass_call_bytes, "ms": ms_per_step,
                               "achieved": (pass_red_bytes + pass_call_bytes) / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": (pass_red_bytes + pass_call_bytes) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
