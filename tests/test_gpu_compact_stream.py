@@ -196,3 +196,30 @@ def test_last_chunk_of_a_shard_goes_slice_major(ctx, P, S, n, cuts, extras, slim
         ctx.set_tuning(0)
         ctx.set_slice_format(False)
         ctx.set_record_layout("i32")
+
+
+def test_streamed_chunks_over_position_ranges(ctx):
+    """The table carry (TAB) and the position ranges together: a uint16 cohort in three chunks through the summary table with the
+    launches cut into two / three position ranges (each range reads and writes its own positions of the table); the last launch
+    finalises.  Error table of the oracle; a joining call (flags) before the table is looked at."""
+    P, S, cuts = 20_000, 48, (0, 16, 32, 48)
+    rng = np.random.default_rng(7)
+    recs = _cohort(P, S, rng)[0][:, :P]
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    for n in (2, 3):
+        acc = ctx.new_acc(P)
+        ctx.set_tuning(1, groups=1)
+        ctx.set_ranges(n)
+        try:
+            fin = None
+            for ci in range(3):
+                lo, hi = cuts[ci], cuts[ci + 1]
+                rec = ctx.records(_pack(ctx, np.ascontiguousarray(recs[lo:hi]), "u16"), "u16", hi - lo)
+                fin = ctx.error_reduce_records(rec, P, acc, 0.002, 100, first_sample=lo, accumulate=ci > 0, finalize=ci == 2, summary=True)
+                assert ctx.last_reduce_kernel() == COMPACT["u16"]
+            assert ctx.flags() == 0  # joins the ranges
+        finally:
+            ctx.set_ranges(1)
+            ctx.set_tuning(0)
+        _summary_equal(acc, ref)
+        assert_final_equal(fin, orc.error_finalize(ref))
