@@ -293,7 +293,8 @@ extern "C" int ampli_ranges_join(ampli_ctx *ctx)
 extern "C" int ampli_range_event_record(ampli_ctx *ctx, int32_t range, void *ev)
 {
     if (!ctx || !ev || range < 0 || range >= ctx->n_ranges) return AMPLI_E_INVALID;
-    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, lane_stream(ctx, range)));
+    // without ranges (n_ranges = 1) there are no lanes: range 0 is the context's own stream
+    HIP_TRY(ctx, hipEventRecord((hipEvent_t)ev, ctx->n_ranges > 1 ? lane_stream(ctx, range) : main_stream(ctx)));
     return AMPLI_OK;
 }
 

@@ -398,6 +398,12 @@ def test_ranges_leave_other_shapes_alone(ctx16):
         assert torch.equal(fin.thr.view(torch.int32), whole.thr.view(torch.int32))
         assert torch.equal(res["call_mask"], wres["call_mask"]) and torch.equal(full["call_mask"], wfull["call_mask"])
         assert ctx16.n_calls_total(res) == ctx16.n_calls_total(wres)
+        ctx16.set_ranges(1)  # without ranges, "range 0" is the context's own stream
+        ea, eb = ctx16.event(), ctx16.event()
+        ctx16.range_record(0, ea)
+        ctx16.error_estimate(nd, P, 0.002, 100, out=fin)
+        ctx16.range_record(0, eb)
+        assert ctx16.elapsed_ms(ea, eb) > 0
     finally:
         ctx16.set_ranges(1)
         ctx16.set_tuning(0)
