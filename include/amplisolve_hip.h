@@ -492,10 +492,11 @@ int ampli_last_reduce_kernel(const ampli_ctx *ctx);
  * Position ranges on concurrent streams (round 5).  A resident panel is rarely a whole number of rounds of workgroups (config 3:
  * 1563 tiles of 64 positions on 1280 resident workgroups of error_reduce), and a launch's partly filled last round runs at a
  * fraction of the chip.  With n_ranges > 1 (at most 4) ampli_error_estimate / ampli_error_reduce_records and ampli_poisson_call /
- * _records (prefilter mode) cut the panel into n tile-aligned ranges of positions, each on a stream the context
- * owns (the context's own stream only forks into them and joins them), each range's poisson_call behind its own error_estimate (a position's thresholds are all a
- * record of that position needs).  Over BACK-TO-BACK passes on independent batches one range's poisson_call and another's
- * error_reduce then fill each other's thin rounds (config 3: 0.146 -> 0.12-0.13 ms per pass); a single pass gains nothing -- the
+ * _records (prefilter mode) cut the panel into n tile-aligned ranges of positions, each on a stream the context owns (the
+ * context's own stream only forks into them and joins them), each range's poisson_call behind its own error_estimate (a position's
+ * thresholds are all a record of that position needs).  Over BACK-TO-BACK passes on independent batches one range's poisson_call
+ * and another's error_reduce then fill each other's thin rounds (config 3: 0.143-0.155 -> 0.132-0.139 ms per pass; more than two
+ * ranges buy nothing more); a single pass gains nothing -- the
  * join at its end costs what the overlap inside it saves -- so the command lines do not use it.  Outputs are the same arrays,
  * bit for bit; the call list's shards are dealt to the ranges (range k appends to shards [32 k / n, 32 (k + 1) / n)), so a shard
  * fills n times faster than without ranges.
