@@ -93,7 +93,7 @@ static inline int check_launch(ampli_ctx *ctx, const char *what)
 
 // Every ordinary entry point enqueues on main_stream(ctx): if position ranges are still running on their own streams
 // (ampli_set_ranges), the context's stream first waits for them -- so whatever follows sees their outputs and may overwrite their
-// inputs.  Only the range-aware launches of ampli_error_estimate / ampli_poisson_call use ctx->stream (lane 0) as it is.
+// inputs.  Only the fork / join of the ranges and the capture check touch ctx->stream as it is.
 int ampli_ranges_join_internal(ampli_ctx *ctx);
 static inline hipStream_t main_stream(ampli_ctx *ctx)
 {

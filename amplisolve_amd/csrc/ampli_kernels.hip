@@ -151,8 +151,8 @@ extern "C" int ampli_wait_calls(ampli_ctx *ctx)
 
 // ---------------------------------------------------------------------------
 // Position ranges on concurrent streams (ampli_set_ranges; include/amplisolve_hip.h).  With n > 1 ranges ampli_error_estimate and
-// ampli_poisson_call (prefilter mode) cut the panel into n tile-aligned ranges of positions; range 0 runs on the context's stream,
-// range k on a stream of its own, each range's poisson_call behind its own error_estimate.  The section opens with a fork (the
+// ampli_poisson_call (prefilter mode) cut the panel into n tile-aligned ranges of positions, every range on a stream the context
+// created for it (lane_stream below), each range's poisson_call behind its own error_estimate.  The section opens with a fork (the
 // lanes' streams wait for everything enqueued on the context's stream so far) and stays open across calls: back-to-back passes
 // over independent batches overlap -- one range's poisson_call and another's error_reduce fill each other's partly filled rounds
 // of workgroups.  It closes (the context's stream waits for every lane) at the next ordinary call: main_stream().
