@@ -168,6 +168,20 @@ inline bool parse_int(const char *&p, const char *e, int64_t &v)
 // is the header (EE:1113, VC:721).  fw = X - Xrs (EE:1155-1158).  The first line of a panel position goes straight
 // into dst (this sample's row of P records in `layout`, pre-filled as absent by this function); further lines of the
 // same position (overlapping amplicons) are returned as extras.  line: optional [P] data-line index of the primaries.
+//
+// Two tokenisers feed one consumer.  The PLAIN one is the definition: line end by memchr, whitespace = ' ' '\t' '\r', a token = a run of
+// anything else, an integer = optional sign + 1..17 digits (whatever follows the digits starts the next token).  The FAST one (round 5)
+// reads a line once, left to right, and only accepts what the plain one provably reads the same way: no leading whitespace, every
+// separator exactly one '\t', integers unsigned with 1..17 digits directly followed by their separator; at anything else -- a
+// space, a sign, "12.5", a short line, a carriage return inside the line, a blank line -- it hands THAT line to the plain tokeniser.
+// It needs no bounds checks: it runs only up to the file's last '\n', and every one of its loops stops at a '\n'.
+// AMPLISOLVE_PARSER=plain switches it off (tests/test_stream_ingest.py compares the two on hostile files).
+static bool fast_tokeniser_enabled() // asked once per file
+{
+    const char *e = getenv("AMPLISOLVE_PARSER");
+    return !(e && strcmp(e, "plain") == 0);
+}
+
 void parse_file_text(const Panel &panel, const std::string &path, int layout, char *dst, int32_t *line, FileResult &out)
 {
     const int64_t P = panel.P();
@@ -186,12 +200,7 @@ void parse_file_text(const Panel &panel, const std::string &path, int layout, ch
     if (len && base == MAP_FAILED) { close(fd); out.error = "mmap failed for " + path; out.error_code = AMPLI_E_INVALID; return; }
     if (len) madvise((void *)base, len, MADV_SEQUENTIAL);
     const char *cur = base, *end = base + len;
-    auto bail = [&](const std::string &msg) {
-        out.error = msg;
-        out.error_code = AMPLI_E_RANGE;
-        if (base) munmap((void *)base, len);
-        close(fd);
-    };
+    struct Unmap { const char *b; size_t n; int fd; ~Unmap() { if (b) munmap((void *)b, n); close(fd); } } unmap{base, len, fd};
     // header
     while (cur < end && *cur != '\n') ++cur;
     if (cur < end) ++cur;
@@ -200,78 +209,145 @@ void parse_file_text(const Panel &panel, const std::string &path, int layout, ch
     int last_cid = -1;
     int64_t prev_p = -2;
     int32_t line_idx = 0;
+    // one tokenised data line: chromosome [c0, c0 + clen), coordinate, v = A C G T RD Ars Crs Grs Trs.  false = the file is refused (out.error set)
+    auto consume = [&](const char *c0, const size_t clen, const int64_t pos, const int64_t *v) -> bool {
+        if (last_cid < 0 || clen != last_chrom.size() || memcmp(c0, last_chrom.data(), clen) != 0) {
+            last_chrom.assign(c0, clen);
+            auto it = panel.chrom_id.find(last_chrom);
+            last_cid = it == panel.chrom_id.end() ? -1 : it->second;
+            if (last_cid < 0) last_chrom.clear();
+        }
+        int64_t pi = -1;
+        if (last_cid >= 0) {
+            // files follow the panel order: try the successor of the previous hit first
+            const int64_t nx = prev_p + 1;
+            if (nx >= 0 && nx < P && panel.pos_coord[nx] == pos && panel.pos_chrom[nx] == last_cid) pi = nx;
+            else {
+                auto it = panel.index.find(((uint64_t)(uint32_t)last_cid << 32) | (uint32_t)pos);
+                if (it != panel.index.end()) pi = it->second;
+            }
+        }
+        if (pi < 0) {
+            ++out.n_off;
+            return true;
+        }
+        prev_p = pi;
+        const int64_t A = v[0], C = v[1], G = v[2], T = v[3], RD = v[4];
+        const int64_t w[8] = {A - v[5], C - v[6], G - v[7], T - v[8], v[5], v[6], v[7], v[8]};
+        int32_t rec[8];
+        for (int j = 0; j < 8; ++j) {
+            // 0 <= Xrs <= X and everything inside int32: anything else is not a read count (AMPLI_E_RANGE, as
+            // include/amplisolve_hip.h promises of the packer)
+            if (w[j] < 0 || w[j] > INT32_MAX) {
+                out.error = path + ": data line " + std::to_string(line_idx + 1) + ": a strand count is negative (reverse count above the total) or beyond int32";
+                out.error_code = AMPLI_E_RANGE;
+                return false;
+            }
+            if (w[j] > out.max_count) out.max_count = w[j];
+            if (w[j] > max_count) out.overflows = true;
+            rec[j] = (int32_t)w[j];
+        }
+        const uint32_t k = occ[pi]++;
+        if (A + C + G + T != RD) { // EE:1178-1181, VC:762-765: such a line is used with its own RD column (EE:1229, VC:895)
+            ++out.n_irregular;
+            if (RD < INT32_MIN || RD > INT32_MAX) {
+                out.error = path + ": data line " + std::to_string(line_idx + 1) + ": RD beyond int32";
+                out.error_code = AMPLI_E_RANGE;
+                return false;
+            }
+            out.irregular.push_back(Irregular{0u, (uint32_t)pi, k, (int32_t)RD});
+        }
+        if (k == 0) {
+            if (!out.overflows) put_record(layout, dst + (size_t)pi * rb, rec);
+            if (line) line[(size_t)pi] = line_idx;
+        } else {
+            Extra e;
+            e.p = (uint32_t)pi; e.k = k; e.line = line_idx;
+            memcpy(e.rec, rec, sizeof rec);
+            out.extras.push_back(e);
+        }
+        return true;
+    };
+    // the plain tokeniser on the line [cur, le)
+    auto plain_line = [&](const char *lb, const char *le) -> bool {
+        const char *p = skip_ws(lb, le);
+        if (p >= le) return true; // a blank line is no line at all
+        ++out.n_lines;
+        const char *c0 = p, *c1 = skip_tok(p, le);
+        p = c1;
+        int64_t pos, v[9];
+        bool ok = parse_int(p, le, pos);
+        for (int i = 0; ok && i < 4; ++i) { p = skip_ws(p, le); const char *q = skip_tok(p, le); ok = q > p; p = q; }
+        for (int i = 0; ok && i < 9; ++i) ok = parse_int(p, le, v[i]);
+        if (!ok) ++out.n_malformed;
+        else if (!consume(c0, (size_t)(c1 - c0), pos, v)) return false;
+        ++line_idx;
+        return true;
+    };
+    // every line that ends in a '\n' may go through the fast tokeniser; what follows the file's last '\n' (a last line without one) may not
+    const char *fast_end = cur;
+    if (fast_tokeniser_enabled() && cur < end) {
+        const char *last_nl = (const char *)memrchr(cur, '\n', (size_t)(end - cur));
+        if (last_nl) fast_end = last_nl + 1;
+    }
+    auto is_sep = [](const unsigned char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; };
+    // unsigned integer of 1..17 digits at p, directly followed by `term`: value in x, p behind the terminator
+    auto fast_int = [](const char *&p, const char term, int64_t &x) -> bool {
+        const char *s = p;
+        uint64_t a = 0;
+        unsigned d;
+        while ((d = (unsigned)(unsigned char)*p - '0') <= 9u) { a = a * 10 + d; ++p; }
+        if (p == s || p - s > 17 || *p != term) return false;
+        x = (int64_t)a;
+        ++p;
+        return true;
+    };
+    while (cur < fast_end) {
+        const char *p = cur;
+        bool ok = !is_sep((unsigned char)*p);
+        const char *c0 = p;
+        size_t clen = 0;
+        int64_t pos = 0, v[9];
+        if (ok) {
+            while (!is_sep((unsigned char)*p)) ++p;
+            clen = (size_t)(p - c0);
+            ok = *p == '\t';
+            ++p;
+        }
+        ok = ok && fast_int(p, '\t', pos);
+        for (int i = 0; ok && i < 4; ++i) {
+            const char *t0 = p;
+            while (!is_sep((unsigned char)*p)) ++p;
+            ok = p > t0 && *p == '\t';
+            ++p;
+        }
+        for (int i = 0; ok && i < 8; ++i) ok = fast_int(p, '\t', v[i]);
+        if (ok) { // the last integer: whatever follows its digits belongs to no column
+            const char *s0 = p;
+            uint64_t a = 0;
+            unsigned d;
+            while ((d = (unsigned)(unsigned char)*p - '0') <= 9u) { a = a * 10 + d; ++p; }
+            ok = p > s0 && p - s0 <= 17;
+            v[8] = (int64_t)a;
+        }
+        if (ok) {
+            if (*p != '\n') p = (const char *)memchr(p, '\n', (size_t)(fast_end - p)); // never NULL: fast_end is behind a '\n'
+            ++out.n_lines;
+            if (!consume(c0, clen, pos, v)) return;
+            ++line_idx;
+            cur = p + 1;
+        } else {
+            const char *le = (const char *)memchr(cur, '\n', (size_t)(fast_end - cur));
+            if (!plain_line(cur, le)) return;
+            cur = le + 1;
+        }
+    }
     while (cur < end) {
         const char *le = (const char *)memchr(cur, '\n', (size_t)(end - cur));
         if (!le) le = end;
-        const char *p = skip_ws(cur, le);
-        if (p < le) {
-            ++out.n_lines;
-            const char *c0 = p, *c1 = skip_tok(p, le);
-            p = c1;
-            int64_t pos, v[9];
-            bool ok = parse_int(p, le, pos);
-            for (int i = 0; ok && i < 4; ++i) { p = skip_ws(p, le); const char *q = skip_tok(p, le); ok = q > p; p = q; }
-            for (int i = 0; ok && i < 9; ++i) ok = parse_int(p, le, v[i]);
-            if (!ok) {
-                ++out.n_malformed;
-            } else {
-                const size_t clen = (size_t)(c1 - c0);
-                if (last_cid < 0 || clen != last_chrom.size() || memcmp(c0, last_chrom.data(), clen) != 0) {
-                    last_chrom.assign(c0, clen);
-                    auto it = panel.chrom_id.find(last_chrom);
-                    last_cid = it == panel.chrom_id.end() ? -1 : it->second;
-                    if (last_cid < 0) last_chrom.clear();
-                }
-                int64_t pi = -1;
-                if (last_cid >= 0) {
-                    // files follow the panel order: try the successor of the previous hit first
-                    const int64_t nx = prev_p + 1;
-                    if (nx >= 0 && nx < P && panel.pos_coord[nx] == pos && panel.pos_chrom[nx] == last_cid) pi = nx;
-                    else {
-                        auto it = panel.index.find(((uint64_t)(uint32_t)last_cid << 32) | (uint32_t)pos);
-                        if (it != panel.index.end()) pi = it->second;
-                    }
-                }
-                if (pi < 0) {
-                    ++out.n_off;
-                } else {
-                    prev_p = pi;
-                    const int64_t A = v[0], C = v[1], G = v[2], T = v[3], RD = v[4];
-                    const int64_t w[8] = {A - v[5], C - v[6], G - v[7], T - v[8], v[5], v[6], v[7], v[8]};
-                    int32_t rec[8];
-                    for (int j = 0; j < 8; ++j) {
-                        // 0 <= Xrs <= X and everything inside int32: anything else is not a read count (AMPLI_E_RANGE, as
-                        // include/amplisolve_hip.h promises of the packer)
-                        if (w[j] < 0 || w[j] > INT32_MAX)
-                            return bail(path + ": data line " + std::to_string(line_idx + 1) +
-                                        ": a strand count is negative (reverse count above the total) or beyond int32");
-                        if (w[j] > out.max_count) out.max_count = w[j];
-                        if (w[j] > max_count) out.overflows = true;
-                        rec[j] = (int32_t)w[j];
-                    }
-                    const uint32_t k = occ[pi]++;
-                    if (A + C + G + T != RD) { // EE:1178-1181, VC:762-765: such a line is used with its own RD column (EE:1229, VC:895)
-                        ++out.n_irregular;
-                        if (RD < INT32_MIN || RD > INT32_MAX) return bail(path + ": data line " + std::to_string(line_idx + 1) + ": RD beyond int32");
-                        out.irregular.push_back(Irregular{0u, (uint32_t)pi, k, (int32_t)RD});
-                    }
-                    if (k == 0) {
-                        if (!out.overflows) put_record(layout, dst + (size_t)pi * rb, rec);
-                        if (line) line[(size_t)pi] = line_idx;
-                    } else {
-                        Extra e;
-                        e.p = (uint32_t)pi; e.k = k; e.line = line_idx;
-                        memcpy(e.rec, rec, sizeof rec);
-                        out.extras.push_back(e);
-                    }
-                }
-            }
-            ++line_idx;
-        }
+        if (!plain_line(cur, le)) return;
         cur = le < end ? le + 1 : end;
     }
-    if (base) munmap((void *)base, len);
-    close(fd);
 }
 
 // ---------------------------------------------------------------------------------------------------------

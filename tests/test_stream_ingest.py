@@ -244,3 +244,125 @@ def test_binary_record_cache_when_a_file_needs_wider_records(tmp_path, monkeypat
     assert sorted({c["layout"] for c in again}) == [1, 2]  # uint16 chunks and the 24-bit one
     one = co.stream_chunks(d, chunk_bytes=1 << 30, keep_line_no=True)
     assert len(one) == 1 and one[0]["layout"] == 2
+
+
+def _hostile_files(rng, positions, n_files):
+    """ASEQ files whose lines stray from `tab, unsigned integer, tab` in every way the plain tokeniser has an opinion on"""
+    def clean(chrom, pos):
+        A, C, G, T = (int(x) for x in rng.integers(0, 3000, 4))
+        rs = [int(rng.integers(0, v + 1)) for v in (A, C, G, T)]
+        RD = A + C + G + T + (int(rng.integers(1, 9)) if rng.random() < 0.05 else 0)
+        return [chrom, str(pos), "rs1", "0.1", "A", "G", str(A), str(C), str(G), str(T), str(RD)] + [str(x) for x in rs]
+
+    files = {}
+    for f in range(n_files):
+        out = []
+        for chrom, pos in positions:
+            r = rng.random()
+            if r < 0.1:
+                continue  # position absent from this file
+            for _ in range(1 + (rng.random() < 0.1)):  # some positions listed twice
+                tok = clean(chrom, pos)
+                sep, eol = "\t", "\n"
+                m = rng.random()
+                if m < 0.45:
+                    pass
+                elif m < 0.50:
+                    sep = " "
+                elif m < 0.54:
+                    sep = "\t\t"
+                elif m < 0.58:
+                    eol = "\r\n"
+                elif m < 0.61:
+                    tok[0] = " " + tok[0]  # leading blank
+                elif m < 0.64:
+                    i = int(rng.integers(6, 15))
+                    tok[i] = "+" + tok[i]
+                elif m < 0.67:
+                    tok[int(rng.integers(6, 15))] += ".5"  # a float: the digits, then ".5" starts the next token
+                elif m < 0.70:
+                    tok += ["extra", "columns 1 2"]
+                elif m < 0.73:
+                    tok[-1] += "   "
+                elif m < 0.76:
+                    tok = tok[: int(rng.integers(1, 15))]  # short line
+                elif m < 0.79:
+                    tok[int(rng.integers(6, 15))] = "1" * 18  # beyond the tokeniser's 17 digits
+                elif m < 0.82:
+                    tok[10] = "0" * 12 + "7"  # RD with leading zeros, 13 digits: a line with its own RD column
+                elif m < 0.85:
+                    tok[0] = "chrUn"  # a chromosome the panel does not have
+                elif m < 0.88:
+                    tok[1] = str(pos + 100000)  # a coordinate the panel does not have
+                elif m < 0.90:
+                    tok[int(rng.integers(6, 15))] = "x7"
+                elif m < 0.92:
+                    tok[1] = tok[1] + "abc"
+                elif m < 0.94:
+                    tok[int(rng.integers(2, 6))] = ""  # an empty column: two tabs in a row
+                elif m < 0.96:
+                    tok[-1] += "\t"
+                elif m < 0.98:
+                    tok[-1] += "\r"  # a carriage return that is not the line's end
+                    eol = " \n"
+                else:
+                    tok[-1] = "000" + tok[-1] + "abc"
+                out.append(sep.join(tok) + eol)
+                b = rng.random()
+                if b < 0.03:
+                    out.append("\n")
+                elif b < 0.05:
+                    out.append(" \t \r\n")
+                elif b < 0.06:
+                    out.append("\r\n")
+        text = HEADER + "".join(out)
+        if f % 3 == 1:
+            text = text.rstrip("\n")  # the last line has no newline
+        files[f"H{f}"] = text
+    files["Hempty"] = ""
+    files["Hheader"] = HEADER
+    files["Hnonl"] = HEADER.rstrip("\n")
+    files["Hblank"] = HEADER + "\n\n \n"
+    return files
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_fast_tokeniser_reads_hostile_files_exactly_as_the_plain_one(tmp_path, monkeypatch, seed):
+    """The one-pass tokeniser of csrc/host/aseq.cpp only accepts lines it provably reads as the plain one (memchr + whitespace runs)
+    does and hands every other line to it: same records, extras, RD side list, data-line indices and line statistics on files full
+    of blanks, double tabs, carriage returns, signs, floats, short lines, over-long integers, extra columns and missing final newlines."""
+    rng = np.random.default_rng(seed)
+    positions = [("chr1", 1000 + i) for i in range(120)] + [("chr2", 5 + 3 * i) for i in range(60)]
+    (tmp_path / "panel.bed").write_text("chr1\t1000\t1119\tA1\trs\tG\nchr2\t5\t182\tA2\trs\tG\n")
+    (tmp_path / "ref.txt").write_text("".join(f"chr1\t{p}\tA\n" for p in range(1000, 1120)) + "".join(f"chr2\t{p}\tC\n" for p in range(5, 183)))
+    nd = tmp_path / "N"
+    nd.mkdir()
+    for name, text in _hostile_files(rng, positions, 7).items():
+        (nd / f"{name}.PILEUP.ASEQ").write_bytes(text.encode())
+    bed, ref = str(tmp_path / "panel.bed"), str(tmp_path / "ref.txt")
+    seen = {}
+    for parser in ("plain", "fast"):
+        if parser == "plain":
+            monkeypatch.setenv("AMPLISOLVE_PARSER", "plain")
+        else:
+            monkeypatch.delenv("AMPLISOLVE_PARSER")
+        co = HostCohort(bed, str(nd), refbases_file=ref, keep_line_no=True)
+        sig = [_chunks_signature(co.stream_chunks(str(nd), chunk_bytes=cb, threads=t, keep_line_no=True)) for cb, t in ((1, 1), (1 << 30, 3))]
+        seen[parser] = (co.stats(), co.recs.tobytes(), co.line_no.tobytes(), co.E, sig)
+        co.close()
+    assert seen["plain"][0] == seen["fast"][0], (seen["plain"][0], seen["fast"][0])
+    assert seen["plain"][0]["malformed"] > 20 and seen["plain"][0]["lines"] > 900  # the hostile lines are there
+    assert seen["plain"] == seen["fast"]
+
+
+def test_both_tokenisers_refuse_the_same_line_with_the_same_words(tmp_path, monkeypatch):
+    files = {"S1": [_line(100, 500, 2, 1, 0, (250, 1, 0, 0)), "\n", _line(101, 10, 0, 0, 0, (5, 0, 0, 0)).replace("\t", " ", 1), _line(102, 10, 0, 0, 0, (11, 0, 0, 0)),
+                    _line(103, 10, 0, 0, 0, (1, 0, 0, 0))]}
+    bed, ref, nd = _write_panel(tmp_path, files)
+    said = []
+    for parser in ("plain", None):
+        monkeypatch.setenv("AMPLISOLVE_PARSER", parser) if parser else monkeypatch.delenv("AMPLISOLVE_PARSER")
+        with pytest.raises(AmpliError) as e:
+            HostCohort(bed, nd, refbases_file=ref)
+        said.append(str(e.value))
+    assert said[0] == said[1] and "data line 3:" in said[0] and "negative" in said[0]
