@@ -53,7 +53,12 @@ void PhaseClock::report(std::ostream &os, double wall)
         os << "TIMING2 " << e.name << " " << e.s << (e.critical ? " critical" : " overlapped") << "\n";
         if (e.critical) sum += e.s;
     }
-    os << "TIMING2 unattributed " << wall - sum << " critical\nTIMING2 wall_in_main " << wall << " total" << std::endl;
+    // the wall clock (CLOCK_REALTIME) at this report, for a parent that wants to split what lies outside main() into the time
+    // before main was entered and the time after the report (process teardown)
+    const double epoch = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    os << "TIMING2 unattributed " << wall - sum << " critical\nTIMING2 wall_in_main " << wall << " total\nTIMING2 epoch_at_report "
+       << std::fixed << std::setprecision(6) << epoch << " total" << std::endl;
+    os.unsetf(std::ios::fixed);
 }
 
 namespace {
@@ -272,6 +277,21 @@ size_t chunk_bytes_setting()
     if (const char *e = getenv("AMPLISOLVE_CHUNK_BYTES")) return (size_t)std::max(1ll, atoll(e)); // tests: down to one sample per chunk
     return mb << 20;
 }
+
+// Host ring slots.  The consumer needs the device context before it can take a chunk, and the HIP runtime's start-up takes 0.06-0.25 s:
+// with the four slots of rounds 2-4 the parsers of a many-chunk cohort filled them and then stood still until the context was up
+// (config-4-sized cohort, 13 chunks: wall = start-up + the rest of the parsing instead of the larger of the two).  So the ring may
+// hold up to AMPLISOLVE_RING_MB (default 2048) of records in the narrowest layout, at least 4 and at most 64 slots; a slot's memory
+// is only touched when a chunk is packed into it, and a cohort of fewer chunks allocates fewer slots.  The device side keeps four
+// buffers: a chunk is uploaded, consumed and waited for before the next one is taken, so slot k simply uses device buffer k mod 4.
+int ring_slots_setting(const size_t chunk_bytes)
+{
+    size_t mb = 2048;
+    if (const char *e = getenv("AMPLISOLVE_RING_MB")) mb = (size_t)std::max(1, atoi(e));
+    const size_t n = (mb << 20) / std::max<size_t>(1, chunk_bytes);
+    return (int)std::min<size_t>(64, std::max<size_t>(4, n));
+}
+constexpr int kDevSlots = 4;
 
 // AMPLISOLVE_PIN: how a ring buffer reaches the device.  "register" (default): the parsers fill plain page-aligned memory
 // -- they start before the HIP runtime is up -- and the buffer is pinned (hipHostRegister, ~6 ms per 128 MB) the first
@@ -584,7 +604,7 @@ int run_error_estimation(const EeArgs &a)
 
         // the parsers start NOW, into plain memory, while the runtime is still coming up on the side thread
         std::unique_ptr<ChunkStream> first_stream;
-        if (S > 0) first_stream.reset(new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), 4));
+        if (S > 0) first_stream.reset(new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), ring_slots_setting(chunk_bytes_setting())));
         // the host copies of the table are made (their pages touched) while the runtime is still starting, not in front of the download
         const int64_t P = panel.P();
         std::vector<float> rate((size_t)P * 8), germ((size_t)P * 4);
@@ -616,7 +636,7 @@ int run_error_estimation(const EeArgs &a)
         void *ev = nullptr;
         dev.check(dev.api->event_create(&ev), "ampli_event_create");
         struct EvGuard { const HipApi *api; void *ev; ~EvGuard() { if (ev) api->event_destroy(ev); } } evg{dev.api, ev};
-        DevSlot dslots[4];
+        DevSlot dslots[kDevSlots];
         int64_t n_lines = 0;
         double parse_s = 0, wait_s = 0, rec_bytes_up = 0;
         int chunks_done = 0;
@@ -629,7 +649,7 @@ int run_error_estimation(const EeArgs &a)
             n_lines = 0;
             rec_bytes_up = 0;
             if (S > 0) {
-                std::unique_ptr<ChunkStream> own(attempt == 0 ? first_stream.release() : new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), 4));
+                std::unique_ptr<ChunkStream> own(attempt == 0 ? first_stream.release() : new ChunkStream(panel, files, threads, false, chunk_bytes_setting(), ring_slots_setting(chunk_bytes_setting())));
                 ChunkStream &cs = *own;
                 auto next_chunk = [&] {
                     PhaseClock::Scope sc("wait_for_parser");
@@ -638,7 +658,7 @@ int run_error_estimation(const EeArgs &a)
                 for (Chunk *c; (c = next_chunk()) != nullptr;) {
                     if (attempt == 0) // the reference's own message, once per offending line (EE:1178-1181)
                         for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl;
-                    const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, false);
+                    const ampli_records r = upload_chunk(dev, dslots[c->slot % kDevSlots], *c, false);
                     const bool fuse = c->last && !sh; // one device holds the whole panel: finalize in the last chunk's launch
                     const bool only = c->last && chunks_done == 0; // the whole cohort (of this shard) in one chunk: no table
                     if (!only) need_acc();
@@ -856,22 +876,22 @@ int run_variant_calling(const VcArgs &a)
             // tumour files are independent given the error table: they stream through in chunks (parsing of the next
             // chunks overlaps upload + kernels of this one); only the emitted calls come back.  The parsers start before
             // the context is waited for.
-            std::unique_ptr<ChunkStream> own(new ChunkStream(panel, files, threads, true, chunk_bytes_setting(), 4));
+            std::unique_ptr<ChunkStream> own(new ChunkStream(panel, files, threads, true, chunk_bytes_setting(), ring_slots_setting(chunk_bytes_setting())));
             ChunkStream &cs = *own;
             Dev &dev = dev_async.get();
             float *d_thr = dev.upload(thr.data(), thr.size());
             uint8_t *d_ref = dev.upload(panel.ref_code.data(), panel.ref_code.size());
             unsigned long long *d_n = dev.alloc<unsigned long long>(AMPLI_CALL_COUNTER_WORDS);
-            DevSlot dslots[4];
+            DevSlot dslots[kDevSlots];
             auto next_chunk = [&] {
                 PhaseClock::Scope sc("wait_for_parser");
                 return cs.next();
             };
             for (Chunk *c; (c = next_chunk()) != nullptr;) {
                 for (int64_t i = 0; i < c->n_irregular; ++i) std::cout << "malakia paizei edo" << std::endl; // VC:762-765
-                const ampli_records r = upload_chunk(dev, dslots[c->slot], *c, true);
+                const ampli_records r = upload_chunk(dev, dslots[c->slot % kDevSlots], *c, true);
                 const int64_t R = P + c->E;
-                uint8_t *d_mask = (uint8_t *)dslots[c->slot].mask.ensure(dev, (size_t)c->n * R + 4);
+                uint8_t *d_mask = (uint8_t *)dslots[c->slot % kDevSlots].mask.ensure(dev, (size_t)c->n * R + 4);
                 int64_t cap = std::max<int64_t>(1 << 16, (int64_t)c->n * R / 16);
                 ampli_call *d_calls = nullptr;
                 bool done = false;

@@ -127,10 +127,10 @@ def _run_timed(cmd, cwd, env=None):
     """child process with its wall time, the TIMING lines of its stderr and ITS OWN peak RSS (os.wait4)"""
     e = dict(os.environ, **(env or {}))
     with tempfile.TemporaryFile("w+") as fo, tempfile.TemporaryFile("w+") as fe:
-        t0 = time.perf_counter()
+        t0, e0 = time.perf_counter(), time.time()
         pr = subprocess.Popen(cmd, cwd=cwd, env=e, stdout=fo, stderr=fe, text=True)
         _, status, ru = os.wait4(pr.pid, 0)
-        wall = time.perf_counter() - t0
+        wall, e1 = time.perf_counter() - t0, time.time()
         pr.returncode = os.waitstatus_to_exitcode(status)
         fo.seek(0), fe.seek(0)
         out, err = fo.read(), fe.read()
@@ -148,6 +148,10 @@ def _run_timed(cmd, cwd, env=None):
                     timing[f"{w[1]}.{k}"] = float(v)
                 except ValueError:
                     pass
+    ph = timing.get("phases", {})
+    if "epoch_at_report" in ph and "wall_in_main" in ph:  # what lies outside main(), split: before it was entered / after its report
+        ep = ph.pop("epoch_at_report")
+        timing["outside_main"] = {"before_main_s": round(ep - ph["wall_in_main"] - e0, 4), "after_report_s": round(e1 - ep, 4)}
     return pr.returncode, wall, timing, out, err, ru.ru_maxrss / 1024.0
 
 
@@ -204,13 +208,13 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
                                  # Entries without * lie on the main thread's path and add up to wall_in_main; entries with * ran
                                  # on other threads beside it (runtime start-up, parsers, by-product files, ring teardown)
                                  "breakdown_s": ee_t.get("phases"),
-                                 "outside_main_s": round(ee_wall - ee_t.get("phases", {}).get("wall_in_main", ee_wall), 4)},
+                                 "outside_main_s": round(ee_wall - ee_t.get("phases", {}).get("wall_in_main", ee_wall), 4), "outside_main": ee_t.get("outside_main")},
             "variant_calling": {"wall_s": vc_wall, "records": t_rec, "records_per_s": t_rec / vc_wall, "calls": int(vc_t.get("stream.calls", 0)),
                                 "host_peak_rss_MB": vc_rss,
                                 "phases_s": {"table_read": vc_t.get("table"), "stream(parse+upload+call)": vc_t.get("stream"), "parser_busy": vc_t.get("stream.parse_busy"),
                                              "annotate+write": vc_t.get("annotate+write")},
                                 "breakdown_s": vc_t.get("phases"),
-                                "outside_main_s": round(vc_wall - vc_t.get("phases", {}).get("wall_in_main", vc_wall), 4)},
+                                "outside_main_s": round(vc_wall - vc_t.get("phases", {}).get("wall_in_main", vc_wall), 4), "outside_main": vc_t.get("outside_main")},
             "records_per_s": (n_rec + t_rec) / (ee_wall + vc_wall),
             "note": "wall clock of the two executables incl. process start and HIP runtime start-up (0.05-0.25 s each: breakdown_s.runtime_init*; "
                     "the parsers run beside it); the host packer uploads the narrowest record layout the counts fit (bytes_per_record_uploaded)",
