@@ -271,7 +271,7 @@ bool leave_ring_to_exit(const bool process_ends)
 
 size_t chunk_bytes_setting()
 {
-    // about this many bytes of records (in the narrowest layout) per chunk (AMPLISOLVE_CHUNK_MB); three chunks are in flight
+    // about this many bytes of records (in the narrowest layout) per chunk (AMPLISOLVE_CHUNK_MB); ring_slots_setting() chunks may be parsed ahead
     size_t mb = 128;
     if (const char *e = getenv("AMPLISOLVE_CHUNK_MB")) mb = (size_t)std::max(1, atoi(e));
     if (const char *e = getenv("AMPLISOLVE_CHUNK_BYTES")) return (size_t)std::max(1ll, atoll(e)); // tests: down to one sample per chunk
