@@ -1,6 +1,5 @@
 """ON THE GPU BOX: what a config-4-sized AmpliSolveErrorEstimation run spends AFTER main()'s report (0.09-0.14 s against 0.002 s
-at config 3): the same command on the same files, repeated, then after `sync` (dirty pages of the freshly written data set flushed),
-then with the ring left unpinned, then with the orderly exit.  Prints wall / in main / before main / after report per run."""
+at config 3): the same command on the same files, repeated, with the ring left unpinned or smaller, with four parser threads, with the orderly exit.  Prints wall / in main / before main / after report per run."""
 import os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
@@ -18,13 +17,11 @@ def run(tag, extra=None):
     print(f"{tag:28s} rc {rc} wall {wall:.3f} in_main {t.get('phases', {}).get('wall_in_main')} outside {t.get('outside_main')} rss_MB {rss:.0f}", flush=True)
 
 
-run("fresh files, run 1")
-run("fresh files, run 2")
-t0 = time.time(); subprocess.run(["sync"]); print(f"sync took {time.time() - t0:.2f} s", flush=True)
-run("after sync, run 1")
-run("after sync, run 2")
-run("after sync, unpinned ring", {"AMPLISOLVE_PIN": "none"})
-run("after sync, ring 512 MB", {"AMPLISOLVE_RING_MB": "512"})
-run("after sync, orderly exit", {"AMPLISOLVE_EXIT": "orderly"})
-run("after sync, 4 threads", {"AMPLISOLVE_THREADS": "4"})
+subprocess.run(["sync"])
+for rep in range(3):
+    run(f"run {rep + 1}")
+run("unpinned ring", {"AMPLISOLVE_PIN": "none"})
+run("ring of 512 MB", {"AMPLISOLVE_RING_MB": "512"})
+run("4 parser threads", {"AMPLISOLVE_THREADS": "4"})
+run("orderly exit", {"AMPLISOLVE_EXIT": "orderly"})
 subprocess.run(["rm", "-rf", d])
