@@ -1,0 +1,89 @@
+"""Inputs the reference accepts in more than one shape, through the reference's own code and through ours on the CPU: the BED rows in
+any order, with carriage returns, one amplicon listed twice; ASEQ lines in another order than the panel's, lines of positions the
+panel does not have, a position listed three times, a file that is only a header, a sample without a whole amplicon, a chromosome name with underscores in it.  Reference =
+oracle/_ref/ee_ref_driver (storeGermlineStatistics + estimateThresholds + generateFinalOutput compiled where the sources lie, EE:1057-2944);
+ours = the C++ host's panel walk + reader (csrc/host/panel.cpp, aseq.cpp) -> the CPU oracle standing in for the kernels -> the C++
+table writer (csrc/host/table.cpp).  The tables must be the same bytes.  (The kernels against the oracle: the -m gpu tests.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from amplisolve_amd.hostio import HostCohort
+from oracle import pyoracle as orc
+from tests.helpers import write_fresh_panel
+
+pytestmark = pytest.mark.skipif(not os.path.exists(orc.REF_EE_DRIVER), reason="oracle/_ref/ee_ref_driver is absent (make -C oracle where /root/reference exists)")
+HEADER = "chr\tpos\tdbsnp\tMAF\tref\talt\tA\tC\tG\tT\tRD\tArs\tCrs\tGrs\tTrs\n"
+
+
+def _vary(d, rng, what):
+    bed = (d / "p.bed").read_text().splitlines()
+    files = sorted(os.listdir(d / "N"))
+    if "bed_shuffled" in what:
+        rng.shuffle(bed)
+    if "bed_twice" in what:
+        bed.append(bed[0])  # the first amplicon once more: every one of its positions is then a duplicated row of the table
+    (d / "p.bed").write_text("".join(r + ("\r\n" if "bed_crlf" in what else "\n") for r in bed))
+    if "bed_twice" in what or "bed_shuffled" in what:
+        # the by-products of the reference's own panel step (EE:578-670), which its driver takes as files: the walk's reference bases and
+        # the positions the walk visits more than once
+        base = dict((tuple(l.split()[:2]), l.split()[2]) for l in (d / "r.txt").read_text().splitlines())
+        walk = [(c, str(p)) for c, a, b in (r.split("\t")[:3] for r in bed) for p in range(int(a), int(b) + 1)]
+        (d / "r.txt").write_text("".join(f"{c}\t{p}\t{base[(c, p)]}\n" for c, p in walk))
+        seen, dups = set(), []
+        for k in walk:
+            if k in seen and k not in dups:
+                dups.append(k)
+            seen.add(k)
+        (d / "d.txt").write_text("".join(f"{c}\t{p}\n" for c, p in sorted(dups, key=lambda k: (k[0], int(k[1])))))
+    for k, f in enumerate(files):
+        p = d / "N" / f
+        lines = p.read_text().splitlines()[1:]
+        if "aseq_shuffled" in what and k % 2 == 0:
+            rng.shuffle(lines)
+        if "aseq_offpanel" in what:
+            extra = [f"chr9\t{5000 + j}\t.\t.\t.\t.\t500\t1\t0\t2\t503\t250\t0\t0\t1" for j in range(7)] + \
+                    [l.replace("\t", "\t9", 1) for l in lines[:5]]  # a coordinate far off the amplicons, on a chromosome of the panel
+            for e in extra:
+                lines.insert(int(rng.integers(0, len(lines) + 1)), e)
+        if "aseq_triple" in what and k == 1:
+            lines += [lines[3], lines[3].replace("\t5", "\t6", 1), lines[10]]  # lines 3 and 10 again: listed three times / twice
+        if "aseq_header_only" in what and k == 2:
+            lines = []
+        if "aseq_no_amplicon" in what and k == 3:
+            first = bed[0].split("\t")[0:3]
+            lines = [l for l in lines if not (l.split("\t")[0] == first[0] and int(first[1]) <= int(l.split("\t")[1]) <= int(first[2]))]
+        p.write_text(HEADER + "".join(l + "\n" for l in lines))
+
+
+def _rename_chromosome(d):
+    """a chromosome name with underscores: the reference cuts its keys at underscores (EE:1552 `%[^_]_%[^_]_%[^_]`)"""
+    for f in [d / "p.bed", d / "r.txt", d / "d.txt"] + [d / "N" / x for x in os.listdir(d / "N")]:
+        f.write_text(f.read_text().replace("chr7\t", "chr7_KI270803v1_alt\t"))
+
+
+@pytest.mark.parametrize("seed,what", [(21, ("bed_shuffled",)), (27, ("chrom_underscores",)), (22, ("bed_crlf", "aseq_offpanel")), (23, ("bed_twice",)), (24, ("aseq_shuffled", "aseq_triple")),
+                                       (25, ("aseq_header_only", "aseq_no_amplicon", "aseq_offpanel")), (26, ("bed_shuffled", "bed_twice", "aseq_shuffled", "aseq_triple", "aseq_header_only"))])
+def test_table_equals_the_references_on_input_variants(tmp_path, monkeypatch, seed, what):
+    rng = np.random.default_rng(seed)
+    d = tmp_path
+    write_fresh_panel(d, seed, S=7, amplicons=5)
+    if "chrom_underscores" in what:
+        _rename_chromosome(d)
+    _vary(d, rng, what)
+    (d / "o").mkdir()
+    r = subprocess.run([orc.REF_EE_DRIVER, "p.bed", "r.txt", "d.txt", "N", "0.002", "100", "o"], capture_output=True, text=True, cwd=d)
+    assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
+    name = [n for n in os.listdir(d / "o") if n.startswith("positionSpecificNoise_")]
+    assert len(name) == 1
+    want = (d / "o" / name[0]).read_bytes()
+    monkeypatch.chdir(d)  # the same directory literal as the reference's run: the sample visit order hangs on it (a1)
+    co = HostCohort("p.bed", "N", refbases_file="r.txt")
+    acc = orc.error_reduce(co.recs, co.P, 0.002, 100, E=co.E, dup_off=co.dup_off)
+    fin = orc.error_finalize(acc)
+    co.write_error_table(fin["rate"], fin["code"], fin["germ_val"].astype(np.float32), fin["germ_present"], "ours.txt")
+    got = (d / "ours.txt").read_bytes()
+    assert len(want) > 10_000
+    assert got == want
