@@ -87,3 +87,76 @@ def test_table_equals_the_references_on_input_variants(tmp_path, monkeypatch, se
     got = (d / "ours.txt").read_bytes()
     assert len(want) > 10_000
     assert got == want
+
+
+@pytest.mark.skipif(not os.path.exists(getattr(orc, "REF_VC_DRIVER", "")), reason="oracle/_ref/vc_ref_driver is absent")
+@pytest.mark.parametrize("seed,what", [(31, ("bed_twice", "aseq_triple")), (32, ("bed_shuffled", "chrom_underscores")), (33, ("bed_crlf", "aseq_offpanel", "aseq_header_only"))])
+def test_calling_side_reads_those_tables_as_the_reference_does(tmp_path, seed, what):
+    """The calling program's view of the table the reference writes for such a panel: our reader's reference cell, duplicate flag,
+    threshold and germ-max cells == the four maps the reference's own storeInputFile fills (VC:430-576), its by-product VCF byte for
+    byte, and the 10-mers / homopolymer flag of every position x 4 substituted bases == the reference's find_kmer_down / find_kmer_up /
+    homopolymerTest (VC:3307-3718) -- live, on fresh tables (tests/test_oracle_golden.py does the same on ten committed ones)."""
+    from amplisolve_amd.hostio import ErrorTable
+
+    rng = np.random.default_rng(seed)
+    d = tmp_path
+    write_fresh_panel(d, seed, S=5, amplicons=4)
+    if "chrom_underscores" in what:
+        _rename_chromosome(d)
+    _vary(d, rng, what)
+    (d / "o").mkdir()
+    r = subprocess.run([orc.REF_EE_DRIVER, "p.bed", "r.txt", "d.txt", "N", "0.002", "100", "o"], capture_output=True, text=True, cwd=d)
+    assert r.returncode == 0
+    table = "o/" + [n for n in os.listdir(d / "o") if n.startswith("positionSpecificNoise_")][0]
+    maps = subprocess.run([orc.REF_VC_DRIVER, "maps", table, "ref_dummy.vcf"], capture_output=True, cwd=d)
+    ctx = subprocess.run([orc.REF_VC_DRIVER, "context", table, "ref_dummy2.vcf"], capture_output=True, cwd=d)
+    assert maps.returncode == 0 and ctx.returncode == 0
+    t = ErrorTable(str(d / table), dummy_vcf=str(d / "our_dummy.vcf"))
+    lines = {"R": [], "D": [], "T": [], "G": []}
+    for p in range(t.P):
+        c, x = t.key(p)
+        key = f"{c}_{x}"
+        lines["R"].append(f"{key} {t.cell(p, 0)}")
+        if t.dup[p]:
+            lines["D"].append(f"{key} {x}")
+        for nt in range(4):
+            lines["T"].append(f"{key}_{'ACGT'[nt]} {t.cell(p, 1 + nt)}")
+            lines["G"].append(f"{key}_{'ACGT'[nt]} {t.cell(p, 5 + nt)}")
+    ours = "".join(f"{tag} {l}\n" for tag in "RDTG" for l in sorted(lines[tag])).encode()
+    assert ours == maps.stdout and len(ours.splitlines()) > 5000
+    assert (d / "our_dummy.vcf").read_bytes() == (d / "ref_dummy.vcf").read_bytes()
+    want = ctx.stdout.decode().splitlines()
+    assert len(want) == t.P
+    for p, w in enumerate(want):
+        f = w.split(" ")
+        c, x = t.key(p)
+        assert (f[0], f[1], f[2]) == ("C", c, str(x))
+        for i, sub in enumerate("ACGT"):
+            down, up, flag = t.context(p, sub)
+            assert (down, up, str(flag)) == (f[3], f[4], f[5 + i]), (w, sub)
+
+
+@pytest.mark.skipif(not os.path.exists(getattr(orc, "REF_VC_DRIVER", "")), reason="oracle/_ref/vc_ref_driver is absent")
+@pytest.mark.parametrize("n,seed", [(1, 1), (7, 2), (13, 3), (60, 4), (200, 5)])
+def test_visit_order_of_freshly_named_files(tmp_path, monkeypatch, n, seed):
+    """a1 live: the order the files of a directory are visited in is the iteration order of the reference's own unordered_map of
+    {listed path -> sample name} (VC:387-394, 580-627, 672; EE twin EE:552-559, 794-841) -- for file names of any length and for
+    counts on both sides of the map's rehash points, not only for the committed fixtures."""
+    from amplisolve_amd.hostio import sample_order
+
+    rng = np.random.default_rng(seed)
+    d = tmp_path / "T"
+    d.mkdir()
+    alphabet = list("ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789-.")
+    names = set()
+    while len(names) < n:
+        names.add("".join(rng.choice(alphabet, int(rng.integers(1, 24)))).lstrip(".-") or "x")
+    for nm in names:
+        (d / f"{nm}.PILEUP.ASEQ").write_text("chr\tpos\n")
+    (d / "notes.txt").write_text("not an ASEQ file\n")
+    monkeypatch.chdir(tmp_path)
+    r = subprocess.run([orc.REF_VC_DRIVER, "order", "T", "list.txt"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0
+    want = [l.split("\t")[0] for l in r.stdout.splitlines()]
+    assert sorted(want) == sorted(names)
+    assert sample_order("T") == want
