@@ -730,8 +730,16 @@ def main():
             sliced = False
             args.merge = "allreduce"
             merger = TableMerger(P, world, ctx.device, ctx.gm_merge, pack=ctx.acc_pack, unpack=ctx.acc_unpack)
+    ranges_fallback = None
     if n_ranges > 1:
         ctx.set_ranges(n_ranges)
+        if not ctx.ranges_concurrent() or os.environ.get("BENCH_FORCE_RANGES_FALLBACK"):  # (the variable: a rehearsal of this branch)
+            # HIP put two of the ranges' streams on one hardware queue and eight replacements did not help (ampli_set_ranges): such
+            # ranges run one after the other, slower than whole launches on one stream -- time the one-stream pass instead
+            ranges_fallback = {"requested": n_ranges, "used": 1, "reason": "ampli_ranges_concurrent() == 0: the ranges' streams were not seen to overlap on this box"}
+            print(f"position ranges: the streams of {n_ranges} ranges do not overlap on this box; the timed region runs whole launches on one stream", file=sys.stderr)
+            ctx.set_ranges(1)
+            n_ranges = 1
     run_steps(args.warmup, False)
     fence()
     if sliced and slim:
@@ -1204,7 +1212,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["name"], "positions": P, "normals_per_gpu": S, "tumours_per_gpu": T, "normals_total": S_total, "tumours_total": T_total, "depth": depth,
                        "C_value": 0.002, "coverage_cutoff": 100, "poisson_mode": args.mode, "streams": args.streams if not multi else 1,
-                       "position_ranges": n_ranges,
+                       "position_ranges": n_ranges, **({"position_ranges_fallback": ranges_fallback} if ranges_fallback else {}),
                        "parallelism": f"tumour+normal sample shards x{world} ({'the fixed job split' if cfg['strong'] else 'one shard of the configuration per GPU'})" + (("; per batch: RCCL reduce-scatter of the sums + all-to-all of the germ-max pairs by position slice, finalize of the own slice, all-gather of the error table -- one round of collectives per group of independent batches, three groups in flight" if sliced else "; one packed RCCL all-reduce + all-gather of the germ-max regions per batch, overlapped with the neighbouring batches") if multi else ""),
                        "merge": (args.merge if multi else None), "batches_per_exchange": (G if sliced else None),
                        "rehearsal": ("N>1 code path forced on one rank (--force-dist)" if args.force_dist and world == 1 else None),

@@ -89,8 +89,11 @@ def test_bench_line_at_one_gpu_has_the_contract_fields():
     assert d["roofline_whole_rounds"]["frac"] > 0
     # config 2 is 157 tiles: two ranges of >= 2 tiles apply; the timed region ran them inside the library, the block behind it repeats the
     # pass on one stream and compares the outputs
-    assert d["config"]["position_ranges"] == 2 and d["ranges"]["n"] == 2 and len(d["ranges"]["error_reduce_ms"]) == 2
-    assert d["one_stream"]["same_outputs_as_the_timed_region"] is True and d["roofline_overlapped"]["launches_per_step"] == 2
-    assert abs(d["roofline"]["avg_ms"] - max(d["one_stream"]["error_reduce_ms"], d["one_stream"]["poisson_call_ms"])) < 1e-9
+    if "position_ranges_fallback" in d["config"]:  # a box on which two streams of the library could not be made to overlap: whole launches, said so
+        assert d["config"]["position_ranges"] == 1 and d["config"]["position_ranges_fallback"]["requested"] == 2
+    else:
+        assert d["config"]["position_ranges"] == 2 and d["ranges"]["n"] == 2 and len(d["ranges"]["error_reduce_ms"]) == 2
+        assert d["one_stream"]["same_outputs_as_the_timed_region"] is True and d["roofline_overlapped"]["launches_per_step"] == 2
+        assert abs(d["roofline"]["avg_ms"] - max(d["one_stream"]["error_reduce_ms"], d["one_stream"]["poisson_call_ms"])) < 1e-9
     assert 0 < d["roofline_pass"]["frac"] < 1
     assert d["sustained"]["passes"] == 40 and d["cold_hbm"]["batches"] == 2
