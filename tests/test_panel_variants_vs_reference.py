@@ -160,3 +160,32 @@ def test_visit_order_of_freshly_named_files(tmp_path, monkeypatch, n, seed):
     want = [l.split("\t")[0] for l in r.stdout.splitlines()]
     assert sorted(want) == sorted(names)
     assert sample_order("T") == want
+
+
+@pytest.mark.parametrize("seed,what,err", [(41, ("bed_shuffled",), "0.01"), (42, ("bed_twice", "bed_crlf"), "0.0375"), (43, ("chrom_underscores",), "1e-3"),
+                                           (44, ("bed_shuffled", "bed_twice"), "-1"), (45, (), "0.5x"), (46, ("bed_crlf",), "2")])
+def test_default_table_of_such_panels_through_the_command_line(tmp_path, seed, what, err):
+    """germline_dir=not_available (EE:472-506, generateFinalOutput_default EE:2948-3043; no GPU in this mode): the drop-in executable
+    beside the reference's own code on fresh panels in those shapes and default_error strings as main() converts them (atof; <= 0 -> 0.01)."""
+    rng = np.random.default_rng(seed)
+    d = tmp_path
+    write_fresh_panel(d, seed, S=2, amplicons=6)
+    if "chrom_underscores" in what:
+        _rename_chromosome(d)
+    _vary(d, rng, what)
+    (d / "o").mkdir()
+    import ctypes as C
+
+    libc = C.CDLL(None)
+    libc.atof.restype = C.c_double
+    v = libc.atof(err.encode())
+    conv = repr(float(np.float32(v))) if v > 0 else "0.01"  # what main() hands on (EE:353-363): atof into a float, 0.01 for a value <= 0
+    r = subprocess.run([orc.REF_EE_DRIVER, "--default", "p.bed", "r.txt", "d.txt", conv, "o"], capture_output=True, text=True, cwd=d)
+    assert r.returncode == 0, r.stdout[-300:] + r.stderr[-300:]
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "amplisolve_amd", "bin", "AmpliSolveErrorEstimation")
+    q = subprocess.run([exe, "panel_design=p.bed", "reference_genome=unused.fa", "germline_dir=not_available", "C_value=0.002", "coverage_cutoff=100",
+                        f"default_error={err}", "output_dir=q"], capture_output=True, text=True, cwd=d,
+                       env=dict(os.environ, AMPLISOLVE_STRICT_EXIT="1", AMPLISOLVE_REFBASES_FILE="r.txt"))
+    assert q.returncode == 0, q.stdout[-300:] + q.stderr[-300:]
+    want, got = (d / "o" / "positionSpecificNoise_default.txt").read_bytes(), (d / "q" / "positionSpecificNoise_default.txt").read_bytes()
+    assert len(want) > 5000 and got == want
