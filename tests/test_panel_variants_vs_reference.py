@@ -50,6 +50,12 @@ def _vary(d, rng, what):
                 lines.insert(int(rng.integers(0, len(lines) + 1)), e)
         if "aseq_triple" in what and k == 1:
             lines += [lines[3], lines[3].replace("\t5", "\t6", 1), lines[10]]  # lines 3 and 10 again: listed three times / twice
+        if "aseq_own_rd" in what:  # lines whose RD column is not A+C+G+T (EE:1178-1181: used with their own RD, EE:1229), some of them 0
+            for i in range(len(lines)):
+                if rng.random() < 0.04:
+                    tok = lines[i].split("\t")
+                    tok[10] = str(0 if rng.random() < 0.15 else max(0, int(tok[10]) + int(rng.integers(-40, 400))))
+                    lines[i] = "\t".join(tok)
         if "aseq_header_only" in what and k == 2:
             lines = []
         if "aseq_no_amplicon" in what and k == 3:
@@ -65,7 +71,7 @@ def _rename_chromosome(d):
 
 
 @pytest.mark.parametrize("seed,what", [(21, ("bed_shuffled",)), (27, ("chrom_underscores",)), (22, ("bed_crlf", "aseq_offpanel")), (23, ("bed_twice",)), (24, ("aseq_shuffled", "aseq_triple")),
-                                       (25, ("aseq_header_only", "aseq_no_amplicon", "aseq_offpanel")), (26, ("bed_shuffled", "bed_twice", "aseq_shuffled", "aseq_triple", "aseq_header_only"))])
+                                       (25, ("aseq_header_only", "aseq_no_amplicon", "aseq_offpanel")), (26, ("bed_shuffled", "bed_twice", "aseq_shuffled", "aseq_triple", "aseq_header_only")), (28, ("aseq_own_rd",)), (29, ("aseq_own_rd", "aseq_triple", "bed_twice"))])
 def test_table_equals_the_references_on_input_variants(tmp_path, monkeypatch, seed, what):
     rng = np.random.default_rng(seed)
     d = tmp_path
@@ -81,10 +87,12 @@ def test_table_equals_the_references_on_input_variants(tmp_path, monkeypatch, se
     want = (d / "o" / name[0]).read_bytes()
     monkeypatch.chdir(d)  # the same directory literal as the reference's run: the sample visit order hangs on it (a1)
     co = HostCohort("p.bed", "N", refbases_file="r.txt")
-    acc = orc.error_reduce(co.recs, co.P, 0.002, 100, E=co.E, dup_off=co.dup_off)
+    acc = orc.error_reduce(co.recs, co.P, 0.002, 100, E=co.E, dup_off=co.dup_off, rd=co.rd_plane())
     fin = orc.error_finalize(acc)
     co.write_error_table(fin["rate"], fin["code"], fin["germ_val"].astype(np.float32), fin["germ_present"], "ours.txt")
     got = (d / "ours.txt").read_bytes()
+    if "aseq_own_rd" in what:
+        assert co.stats()["irregular"] > 100
     assert len(want) > 10_000
     assert got == want
 
