@@ -80,13 +80,14 @@ def test_table_equals_the_references_on_input_variants(tmp_path, monkeypatch, se
         _rename_chromosome(d)
     _vary(d, rng, what)
     (d / "o").mkdir()
-    r = subprocess.run([orc.REF_EE_DRIVER, "p.bed", "r.txt", "d.txt", "N", "0.002", "100", "o"], capture_output=True, text=True, cwd=d)
+    r = subprocess.run([orc.REF_EE_DRIVER, "p.bed", "r.txt", "d.txt", "N", "0.002", "100", "o", "dump"], capture_output=True, text=True, cwd=d)
     assert r.returncode == 0, r.stdout[-400:] + r.stderr[-400:]
     name = [n for n in os.listdir(d / "o") if n.startswith("positionSpecificNoise_")]
     assert len(name) == 1
     want = (d / "o" / name[0]).read_bytes()
     monkeypatch.chdir(d)  # the same directory literal as the reference's run: the sample visit order hangs on it (a1)
     co = HostCohort("p.bed", "N", refbases_file="r.txt")
+    assert co.names == (d / "dump.order").read_text().split()  # the reference's own visit order of these files (EE:1081)
     acc = orc.error_reduce(co.recs, co.P, 0.002, 100, E=co.E, dup_off=co.dup_off, rd=co.rd_plane())
     fin = orc.error_finalize(acc)
     co.write_error_table(fin["rate"], fin["code"], fin["germ_val"].astype(np.float32), fin["germ_present"], "ours.txt")
