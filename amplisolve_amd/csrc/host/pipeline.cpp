@@ -1040,6 +1040,11 @@ int run_variant_calling(const VcArgs &a)
             PhaseClock::Scope sc("annotate");
             int nt_ann = (int)std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, rows.size() / 64));
             if (const char *e = getenv("AMPLISOLVE_THREADS")) nt_ann = std::max(1, std::min(nt_ann, atoi(e)));
+            // AMPLISOLVE_FISHER=off (validation only): leave the statement of VC:902 out, so that p keeps the -1 of VC:901 -- what the
+            // reference's own callVariants does when it is compiled without its Fisher statements on a box without Boost
+            // (oracle/Makefile, VC_CALL_DROP).  With it every byte of the Summary and the VCF bodies can be compared with that build.
+            const char *fisher_env = getenv("AMPLISOLVE_FISHER");
+            const bool fisher_off = fisher_env && std::string(fisher_env) == "off";
             auto annotate = [&](int tid) {
                 std::ostringstream output, vcf;
                 const size_t i0 = rows.size() * (size_t)tid / (size_t)nt_ann, i1 = rows.size() * (size_t)(tid + 1) / (size_t)nt_ann;
@@ -1056,7 +1061,7 @@ int run_variant_calling(const VcArgs &a)
                     const int alt_fw = c.k_fw, alt_bw = c.k_bw;
                     const char refc = "ACGT"[panel.ref_code[p]], altc = "ACGT"[c.alt];
                     const std::string Flag_Dup = panel.dup[p] ? "YES" : "NO";
-                    const double pf = fisher_two_sided(RD - BW, BW, alt_fw, alt_bw);      // VC:902
+                    const double pf = fisher_off ? -1 : fisher_two_sided(RD - BW, BW, alt_fw, alt_bw); // VC:901-902
                     const std::string Flag_Fisher = pf <= p_value ? "YES" : "NO";         // VC:903-910
                     const std::string Flag_Tier = (alt_fw < 5 || alt_bw < 5) ? "LowQual" : "HighQual"; // VC:912-919
                     const std::string GermlineFlag = "-";                                 // VC:927-935 (map holds a dummy entry only)

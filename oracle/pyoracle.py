@@ -16,6 +16,9 @@ LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 REF_EE_DRIVER = os.path.join(HERE, "_ref", "ee_ref_driver")
 REF_VC_SCORER = os.path.join(HERE, "_ref", "libvc_scorer_ref.so")
 REF_VC_DRIVER = os.path.join(HERE, "_ref", "vc_ref_driver")
+# "callVariants without its Fisher statements" (oracle/Makefile, VC_CALL_DROP): the reference's command line / its phases with a clock
+REF_VC_NOFISHER = os.path.join(HERE, "_ref", "AmpliSolveVariantCalling_noFisher")
+REF_VC_CALL_DRIVER = os.path.join(HERE, "_ref", "vc_call_ref_driver")
 
 _lib = None
 

@@ -203,3 +203,53 @@ def write_fresh_panel(d, seed, depth=None, S=11, amplicons=7):
                 tot = r[w, :4] + r[w, 4:]
                 f.write(f"{c}\t{p}\t.\t.\t.\t.\t{tot[0]}\t{tot[1]}\t{tot[2]}\t{tot[3]}\t{tot.sum()}\t{r[w,4]}\t{r[w,5]}\t{r[w,6]}\t{r[w,7]}\n")
     return len(dups)
+
+
+def write_fresh_tumours(d, seed, T=4, depth=None, spike=0.06, sub="T"):
+    """Tumour ASEQ files d/<sub>/*.PILEUP.ASEQ for the panel write_fresh_panel put in d (the BED walk, so positions of overlapping
+    amplicons are listed twice per file): the synthetic generator's tumour family plus, in `spike` of the cells, an alternative allele
+    moved onto both strands at 0.3-40 % (so that a small panel emits hundreds of calls of every tier: few reads, LowQ, strand-skewed
+    ones).  File names of both shapes the reference's `%[^_]_%[^_]` split sees (VC:701).  Returns the number of lines written."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed ^ 0x7A11)
+    walk = []
+    for row in (d / "p.bed").read_text().splitlines():
+        c, a, b = row.split("\t")[:3]
+        walk += [(c, x) for x in range(int(a), int(b) + 1)]
+    W = len(walk)
+    recs = synth_recs(W, T, seed=seed, depth=int(rng.choice([400, 2000, 6000])) if depth is None else depth, tumour=True).astype(np.int64)
+    # the major allele of every line = the panel's reference base of that walk row (write_fresh_panel draws the bases per unique
+    # position, the records per walk row: without this every position behind the first overlap would be a 100 % variant)
+    refrow = [l.split("\t")[2] for l in (d / "r.txt").read_text().splitlines()]
+    for w in range(W):
+        b = "ACGT".find(refrow[w])
+        if b >= 0:
+            for t in range(T):
+                m = int(np.argmax(recs[t, w, :4] + recs[t, w, 4:]))
+                if m != b and recs[t, w, 0] != np.iinfo(np.int32).min:
+                    recs[t, w, [m, b]] = recs[t, w, [b, m]]
+                    recs[t, w, [4 + m, 4 + b]] = recs[t, w, [4 + b, 4 + m]]
+    (d / sub).mkdir()
+    n = 0
+    for t in range(T):
+        r = recs[t]
+        name = f"P{t:02d}_T{t}_x" if t % 2 else f"K{t:02d}"
+        with open(d / sub / f"{name}.PILEUP.ASEQ", "w") as f:
+            f.write("chr\tpos\tdbsnp\tMAF\tref\talt\tA\tC\tG\tT\tRD\tArs\tCrs\tGrs\tTrs\n")
+            for w, (c, x) in enumerate(walk):
+                if r[w, 0] == np.iinfo(np.int32).min:
+                    continue
+                rec = r[w].copy()
+                if rng.random() < spike:
+                    major, alt = int(np.argmax(rec[:4] + rec[4:])), int(rng.integers(0, 4))
+                    share = float(rng.choice([0.002, 0.003, 0.004, 0.006, 0.01, 0.02, 0.05, 0.2, 0.4]))
+                    for st, skew in ((0, 1.0), (4, float(rng.choice([1.0, 1.0, 0.3, 2.5])))):
+                        k = min(int(rec[st + major]), int(round(rec[st + major] * share * skew)) + int(rng.integers(0, 3)))
+                        if alt != major:
+                            rec[st + major] -= k
+                            rec[st + alt] += k
+                tot = rec[:4] + rec[4:]
+                f.write(f"{c}\t{x}\t.\t.\t.\t.\t{tot[0]}\t{tot[1]}\t{tot[2]}\t{tot[3]}\t{tot.sum()}\t{rec[4]}\t{rec[5]}\t{rec[6]}\t{rec[7]}\n")
+                n += 1
+    return n

@@ -18,9 +18,10 @@ pytestmark = pytest.mark.skipif(not os.path.exists(orc.REF_EE_DRIVER), reason="o
 HEADER = "chr\tpos\tdbsnp\tMAF\tref\talt\tA\tC\tG\tT\tRD\tArs\tCrs\tGrs\tTrs\n"
 
 
-def _vary(d, rng, what):
+def _vary(d, rng, what, sub="N"):
+    """sub: the directory of ASEQ files the aseq_* shapes are applied to (the bed_* shapes rewrite the panel and its by-products)"""
     bed = (d / "p.bed").read_text().splitlines()
-    files = sorted(os.listdir(d / "N"))
+    files = sorted(os.listdir(d / sub))
     if "bed_shuffled" in what:
         rng.shuffle(bed)
     if "bed_twice" in what:
@@ -39,7 +40,7 @@ def _vary(d, rng, what):
             seen.add(k)
         (d / "d.txt").write_text("".join(f"{c}\t{p}\n" for c, p in sorted(dups, key=lambda k: (k[0], int(k[1])))))
     for k, f in enumerate(files):
-        p = d / "N" / f
+        p = d / sub / f
         lines = p.read_text().splitlines()[1:]
         if "aseq_shuffled" in what and k % 2 == 0:
             rng.shuffle(lines)
@@ -66,7 +67,7 @@ def _vary(d, rng, what):
 
 def _rename_chromosome(d):
     """a chromosome name with underscores: the reference cuts its keys at underscores (EE:1552 `%[^_]_%[^_]_%[^_]`)"""
-    for f in [d / "p.bed", d / "r.txt", d / "d.txt"] + [d / "N" / x for x in os.listdir(d / "N")]:
+    for f in [d / "p.bed", d / "r.txt", d / "d.txt"] + [d / sub / x for sub in ("N", "T") if (d / sub).is_dir() for x in os.listdir(d / sub)]:
         f.write_text(f.read_text().replace("chr7\t", "chr7_KI270803v1_alt\t"))
 
 
