@@ -4,7 +4,7 @@ main() included, compiled where it lies minus its Boost include, fisherTest and 
 without its Fisher statements", oracle/Makefile VC_CALL_DROP; p stays -1, the Fisher flag YES).  Two comparisons per case:
   (a) ours with AMPLISOLVE_FISHER=off (p stays -1 too): Summary_Variant_Info.txt and every <sample>.vcf must be the SAME BYTES
       (but the ##fileDate line) -- gate, VAFs, sticky precision, flag order out of the unordered_map, C->G "-" ID, file order;
-  (b) ours as shipped (own Fisher): the Summary but columns 13-14 and the VCFs but the FILTER column must be the same.
+  (b) ours as shipped (own Fisher): the Summary but columns 13-14 and the VCFs but the FILTER and ID columns must be the same.
 The error table of each case comes from the reference's error estimation (ee_ref_driver) and from ours, which must agree first.
 Shapes drawn per case: positions listed twice (overlapping amplicons, always), a BED amplicon listed twice, lines with their own RD
 column, positions listed three times, shuffled lines, off-panel lines, a header-only file, N / soft-masked reference bases, a
@@ -34,8 +34,10 @@ def cut_fisher(b):  # Summary without columns 13-14 (AmpliconEdge_StrandBias, Fi
     return b"\n".join(b"\t".join(l.split(b"\t")[:12] + l.split(b"\t")[14:]) for l in b.split(b"\n"))
 
 
-def cut_filter(b):  # VCF body without the FILTER column (its StrandBias / PositionWithHighNoise tokens hang on Fisher)
-    return b"\n".join(l if l.startswith(b"#") else b"\t".join(l.split(b"\t")[:6] + l.split(b"\t")[7:]) for l in strip_date(b).split(b"\n"))
+def cut_filter(b):
+    """VCF body without the FILTER column (its StrandBias / PositionWithHighNoise tokens hang on Fisher) and without the ID column (the
+    C->G block writes "-" instead of "." when the row is not a PASS, VC:1856 -- and in the build without Fisher every row carries StrandBias)"""
+    return b"\n".join(l if l.startswith(b"#") else b"\t".join(l.split(b"\t")[:2] + l.split(b"\t")[3:6] + l.split(b"\t")[7:]) for l in strip_date(b).split(b"\n"))
 
 
 def soften_reference(d, rng, what):
