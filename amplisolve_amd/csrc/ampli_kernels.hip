@@ -3042,6 +3042,10 @@ static int poisson_prefilter_launch(ampli_ctx *ctx, const int lane_k, hipStream_
         while (rpw > 2 && tiles_all * 4 * ((T + 4 * rpw - 1) / (4 * rpw)) < (long long)ctx->n_cu * 16) rpw = (rpw + 1) / 2;
     if (rpw < 1) rpw = 1;
     long long gy = (T + 4 * rpw - 1) / (4 * rpw);
+    // the same number of row groups with the rows dealt evenly: 128 tumours are 2 x 4 x 16 rows, not 4 x 24 + 4 x 8 -- a thin tumour
+    // shard (config 4 cut eight ways) otherwise ends on workgroups with a third of the others' rows: 64.0 -> 55.4 us for its call
+    // (round 6, tools/experiments/r06_poisson_fused_per_workgroup.log, run 3)
+    if (ctx->pc_rows_per_wave <= 0) rpw = (int)((T + 4 * gy - 1) / (4 * gy));
     while (tiles8 * gy > 0x7fffffffll) { rpw *= 2; gy = (T + 4 * rpw - 1) / (4 * rpw); } // gridDim.x limit
     // queue workspace: T*R/4 items by default (the synthetic and Toy_data panels queue ~0.2 % of the records),
     // or what ampli_set_queue_items asked for plus one workgroup's worth of slack per shard (workgroups are dealt
