@@ -79,6 +79,7 @@ def parse_args():
     ap.add_argument("--event-every", type=int, default=5, help="record the per-kernel HIP events on every n-th timed step (each record costs a few us of stream time)")
     ap.add_argument("--streams", type=int, default=1, help="N = 1 only: independent batches round-robin over this many HIP streams "
                     "(cross-batch overlap; per-kernel times then include contention, so the default stays 1)")
+    ap.add_argument("--no-shard-projection", action="store_true", help="N = 1: skip the projection of config 4's tumour shard (poisson_call over 1024 / N tumours, N = 1, 2, 4, 8)")
     ap.add_argument("--async-drain", action="store_true", help="poisson_call's drain kernel on a side stream (measured: no gain on config 3)")
     ap.add_argument("--records", default="auto", choices=["auto", "i32", "u24", "u16"],
                     help="record layout resident in HBM (identical results): i32 = 8 x int32 = 32 B per record; u24 = 8 x 24 bits = "
@@ -173,6 +174,53 @@ def reference_ee_run(d, normals_dir, out_name):
                 table=os.path.join(d, out_name, "positionSpecificNoise_0.0020.txt"))
 
 
+def reference_vc_call_run(d, H, P, depth, table, T_total):
+    """the reference's own callVariants (oracle/_ref/vc_call_ref_driver: AmpliSolveVariantCalling.cpp compiled -O2 where it lies minus its Boost
+    include, fisherTest and the 12 `p=fisherTest(...)` statements; p stays -1) on tumour files of the workload: `time` mode = storeInputFile ->
+    storeCountList -> callVariants as main() runs them (VC:320-344), a clock around each.  One process = one core; then n processes over a
+    directory split (tumour files are independent), all started together, wall clock of the slowest."""
+    from oracle import pyoracle as orc
+
+    n1 = 6
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nproc = max(1, min(cores, 16))
+    per = 2  # files per process in the split
+    need = max(n1, nproc * per)
+    if H.ampli_host_synth_write_aseq(os.path.join(d, "T").encode(), b"T", P, need, 0, SEED, depth, 1, 0) <= 0:
+        return None
+    files = sorted(os.listdir(os.path.join(d, "T")))
+
+    def stage(name, fs):
+        os.makedirs(os.path.join(d, name), exist_ok=True)
+        for f in fs:
+            os.symlink(os.path.join("..", "T", f), os.path.join(d, name, f))
+        os.makedirs(os.path.join(d, name + "_o", "AmpliSolveVariantCalling_interm_files"), exist_ok=True)
+        return [orc.REF_VC_CALL_DRIVER, "time", table, name, name + "_o", "100", "0.05"]
+
+    rc, wall, tm, out, err, _ = _run_timed(stage("T1", files[:n1]), d)
+    if rc != 0 or "callVariants" not in tm:
+        return None
+    lines1 = sum(sum(1 for _ in open(os.path.join(d, "T", f))) - 1 for f in files[:n1])
+    calls1 = sum(1 for _ in open(os.path.join(d, "T1_o", "Summary_Variant_Info.txt"))) - 1
+    res = dict(files_1_core=n1, records_1_core=lines1, callVariants_s_1_core=tm["callVariants"], storeInputFile_s=tm["storeInputFile"],
+               storeCountList_s=tm.get("storeCountList"), calls_1_core=calls1, tumour_records_per_s_1_core=lines1 / tm["callVariants"], cores=1,
+               what="reference callVariants (VC:633-3304) without its Fisher statements, -O2, in main()'s call order (oracle/ref_vc_call_driver.cpp)")
+    cmds = [stage(f"S{k:02d}", files[k * per:(k + 1) * per]) for k in range(nproc)]
+    t0 = time.perf_counter()
+    prs = [subprocess.Popen(c, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True) for c in cmds]
+    errs = [pr.communicate()[1] for pr in prs]
+    wall_n = time.perf_counter() - t0
+    if any(pr.returncode != 0 for pr in prs):
+        return res
+    cv = [float(ln.split()[2]) for e in errs for ln in e.splitlines() if ln.startswith("TIMING callVariants")]
+    lines_n = sum(sum(1 for _ in open(os.path.join(d, "T", f))) - 1 for f in files[:nproc * per])
+    res.update(processes=nproc, host_cores=cores, files_n_processes=nproc * per, records_n_processes=lines_n, wall_s_n_processes=wall_n,
+               callVariants_s_slowest_process=max(cv) if cv else None,
+               tumour_records_per_s_n_processes=lines_n / max(cv) if cv else lines_n / wall_n,
+               note_n="callVariants' own seconds in the slowest of the processes (each also loads the table: storeInputFile_s, once per process, inside wall_s_n_processes)")
+    return res
+
+
 def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
     """ASEQ text on disk -> positionSpecificNoise table -> Summary / VCFs through the two command lines, timed; the
     reference's error estimation on the same files beside it (all of them when ref_files is None)."""
@@ -255,31 +303,10 @@ def e2e_leg(name, cfg, ref_files=None, keep_dir=None):
 
 
 # ----------------------------------------------------------------------------------------------------
-# CPU baseline leg (rank 0, N = 1): the reference's own code where it builds (error estimation: the whole translation
-# unit; calling: its Poisson scorer, the only part of that translation unit that compiles without Boost), on a bounded
-# sample of the SAME workload, plus the oracle port on both halves.
+# CPU baseline leg (rank 0, N = 1): the reference's own code (error estimation: the whole translation unit; calling: the
+# whole translation unit but its Boost include, fisherTest and the 12 statements that call it -- oracle/Makefile), on a
+# bounded sample of the SAME workload, plus the oracle port on both halves.
 # ----------------------------------------------------------------------------------------------------
-def _scorer_stream(P, Tn, depth, thr, ref):
-    """(k, RD, err) of every scorer call callVariants would make on the first Tn tumours: 3 alts x 2 strands per present
-    record with an ACGT reference (VC:869-896)"""
-    import numpy as np
-
-    from tests.helpers import synth_recs
-
-    recs = synth_recs(P, Tn, seed=SEED, depth=depth, tumour=True).astype(np.int64)
-    present = recs[:, :, 0] != np.iinfo(np.int32).min
-    BW = recs[:, :, 4:].sum(-1)
-    RD = recs.sum(-1)
-    ks, ds, es = [], [], []
-    for nt in range(4):
-        m = present & (ref[None, :] != nt) & (ref[None, :] <= 3)
-        t_i, p_i = np.nonzero(m)
-        ks += [recs[t_i, p_i, nt], recs[t_i, p_i, 4 + nt]]
-        ds += [(RD - BW)[t_i, p_i], BW[t_i, p_i]]
-        es += [thr[0, nt, p_i], thr[1, nt, p_i]]
-    return (np.concatenate(ks).astype(np.int32), np.concatenate(ds).astype(np.int32), np.concatenate(es).astype(np.float32))
-
-
 def cpu_baseline(cfg, thr, ref_code, full=False):
     import numpy as np
 
@@ -316,6 +343,7 @@ def cpu_baseline(cfg, thr, ref_code, full=False):
         open(os.path.join(d, "dups.txt"), "w").close()
         r = reference_ee_run(d, "N", "ref")
         vc_load = None
+        vc_call = None
         if r and os.path.exists(getattr(orc, "REF_VC_DRIVER", "")):
             # the calling half's table load, by the reference's own storeInputFile (VC:430-576, compiled in place without Boost) on the
             # table the reference just wrote for this panel: P rows, four threshold and four germ-max cells each
@@ -326,6 +354,8 @@ def cpu_baseline(cfg, thr, ref_code, full=False):
                                    what="reference storeInputFile (VC:430-576) on the workload's error table, once per AmpliSolveVariantCalling run")
             except Exception:  # noqa: BLE001
                 vc_load = None
+        if r and os.path.exists(getattr(orc, "REF_VC_CALL_DRIVER", "")):
+            vc_call = reference_vc_call_run(d, H, P, depth, os.path.relpath(r["table"], d), T)
         if r:
             ee = dict(records=r["records"], seconds=r["seconds"], records_per_s=r["records_per_s"], cores=1, phases_s=r["phases"],
                       sample=f"{n_ref} of the {S} normal files of the workload ({P} positions each), reference AmpliSolveErrorEstimation.cpp -O2, "
@@ -337,39 +367,22 @@ def cpu_baseline(cfg, thr, ref_code, full=False):
         import shutil
 
         shutil.rmtree(d, ignore_errors=True)
-    # --- the reference's Poisson scorer on the workload's own (k, RD, err) stream --------------------------
-    vc = None
-    if os.path.exists(orc.REF_VC_SCORER):
-        Tn = 8
-        k, rd, e = _scorer_stream(P, Tn, depth, thr, ref_code)
-        with tempfile.TemporaryDirectory(prefix="ampli_sc_") as sd:
-            np.savez(os.path.join(sd, "stream.npz"), k=k, rd=rd, err=e)
-            # its own process: the worker pool must not fork from a process that holds the GPU
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_scorer_bench.py"), os.path.join(sd, "stream.npz")],
-                               capture_output=True, text=True, timeout=600)
-        if r.returncode == 0:
-            m = json.loads(r.stdout.strip().splitlines()[-1])
-            per_record = k.size / (Tn * P)  # scorer calls per tumour record (3 alts x 2 strands on present ACGT records)
-            vc = dict(evaluations=m["evaluations"], seconds_1_core=m["seconds_1_core"], evaluations_per_s_1_core=m["evaluations"] / m["seconds_1_core"],
-                      processes=m["processes"], seconds_n_processes=m["seconds_n_processes"],
-                      evaluations_per_s_n_processes=m["evaluations"] / m["seconds_n_processes"], scorer_calls_per_tumour_record=per_record,
-                      tumour_records_per_s_1_core=m["evaluations"] / m["seconds_1_core"] / per_record,
-                      sample=f"mutationRulesPoissonQualityScore (VC:3834-3884, oracle/_ref/libvc_scorer_ref.so) on the exact (k, RD, err) stream of the "
-                             f"first {Tn} of the {T} tumours: scorer only -- callVariants' parsing and hash look-ups (the bulk of its time) are not in it, "
-                             "the rest of that translation unit needs Boost and cannot be built here")
     out["port"] = port
     out["ee"] = ee
-    out["vc_scorer"] = vc
+    out["vc_callvariants"] = vc_call
     out["vc_table_load"] = vc_load
-    if ee and vc:
+    if ee and vc_call:
         # one figure in the metric's unit: the workload's record mix through the reference's own code on one core
-        t_load = vc_load["seconds"] if vc_load else 0.0
-        t_mix = P * S / ee["records_per_s"] + P * T / vc["tumour_records_per_s_1_core"] + t_load
+        t_load = vc_call["storeInputFile_s"]
+        t_mix = P * S / ee["records_per_s"] + P * T / vc_call["tumour_records_per_s_1_core"] + t_load
         out.update(value=(P * S + P * T) / t_mix, cores=1, kind="reference",
-                   sample=f"reference code on one host core, bounded sample of the same workload: error estimation {ee['records']} records in "
-                          f"{ee['seconds']:.1f} s; calling = Poisson scorer {vc['evaluations']} evaluations in {vc['seconds_1_core']:.1f} s + the table load "
-                          f"(storeInputFile, {t_load:.2f} s once) -- callVariants itself (parsing, hash look-ups) needs Boost and is not in it; value = "
-                          "(normal + tumour records of the workload) / (their time at those rates)")
+                   value_all_cores=(P * S + P * T) / (P * S / ee["records_per_s"] + P * T / vc_call["tumour_records_per_s_n_processes"] + t_load),
+                   sample=f"reference code on one host core, bounded sample of the same workload: error estimation (storeGermlineStatistics + estimateThresholds + "
+                          f"generateFinalOutput) {ee['records']} records in {ee['seconds']:.1f} s; calling = the reference's own callVariants (VC:633-3304, compiled in place "
+                          f"without its 12 fisherTest statements: oracle/Makefile VC_CALL_DROP) on {vc_call['files_1_core']} of the {T} tumour files, "
+                          f"{vc_call['records_1_core']} records in {vc_call['callVariants_s_1_core']:.1f} s, + its table load (storeInputFile, {t_load:.2f} s once); value = (normal + "
+                          f"tumour records of the workload) / (their time at those rates).  value_all_cores: the calling half as {vc_call['processes']} processes over a "
+                          f"directory split (tumour files are independent; the error estimation cannot use more than one core)")
     else:
         out.update(value=port["value"], cores=1, kind="port", sample=port["sample"])
     return out
@@ -902,7 +915,19 @@ def main():
                 ctx.poisson_call(tumours, P, fs.thr, ref_code, 100, mode=mode, call_mask=call_mask, capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
 
             fence()
-            ms_sh, _ = timed_passes(shard_call, 10)
+            # cold calls: the rank's own error_estimate between two of them, events around the call alone (ten calls back to back, as
+            # round 5 timed it, replay a 128-tumour shard of 205 MB out of the 256 MiB Infinity Cache while the one-GPU base reads HBM)
+            esh = [[ctx.event(), ctx.event()] for _ in range(10)]
+            evict_sh = ctx.error_estimate(normals, P, 0.002, 100)
+            for i in range(12):
+                ctx.error_estimate(normals, P, 0.002, 100, out=evict_sh)
+                if i >= 2:
+                    ctx.record(esh[i - 2][0])
+                shard_call()
+                if i >= 2:
+                    ctx.record(esh[i - 2][1])
+            torch.cuda.synchronize()
+            ms_sh = sorted(ctx.elapsed_ms(a, b) for a, b in esh)[5]
             tsh = torch.tensor([ms_sh], dtype=torch.float64, device=ctx.device)
             dist.all_reduce(tsh, op=dist.ReduceOp.MAX)
             tumour_shard = {"tumours_per_gpu": T, "poisson_call_ms_slowest_rank": float(tsh.item()), "R_VC_evals_per_s": P * T_total / (float(tsh.item()) * 1e-3)}
@@ -941,6 +966,57 @@ def main():
                 normals = tumours = None
                 packed = {}
             fence()
+    # north_star's scaling target is worded on the TUMOUR SHARD, which has no exchange step -- so what one of N GPUs would run on config 4
+    # (100 k positions x 1024 tumours, cut N ways along the tumour axis) can be timed on ONE GPU: poisson_call over 1024 / N tumours
+    # against the 1024-tumour call / N, same box, same process, same table.  Every call is COLD: an error_estimate over this run's
+    # normals (>= 400 MB) sits between two calls, so that a 128-tumour shard (205 MB) is not replayed out of the 256 MiB Infinity Cache.
+    shard_proj = None
+    if not multi and lanes is None and not args.no_shard_projection and mode == POISSON_PREFILTER and P == CONFIGS["c4"]["P"] and layout == "u16":
+        T4 = CONFIGS["c4"]["T"]
+        parts = []
+        for lo in range(0, T4, 128):
+            raw = ctx.synth_fill(P, 128, first_sample=lo, seed=SEED, depth=CONFIGS["c4"]["depth"], tumour=True)
+            parts.append(ctx.pack(raw, layout)[0])
+            del raw
+        at = torch.cat(parts)
+        del parts
+        mask4 = torch.empty((T4, P), dtype=torch.uint8, device=ctx.device)
+        f4 = fins[0] if fins[0] is not None else fin
+        evict4 = ctx.error_estimate(normals, P, 0.002, 100)  # a table of its own: f4's thresholds stay what the calls read
+        reps4 = 12
+
+        def shard_ms(tn):
+            e4 = [[ctx.event(), ctx.event()] for _ in range(reps4)]
+            for i in range(reps4 + 2):
+                ctx.error_estimate(normals, P, 0.002, 100, out=evict4)  # pushes the tumours out of the cache
+                if i >= 2:
+                    ctx.record(e4[i - 2][0])
+                ctx.poisson_call(at[:tn], P, f4.thr, ref_code, 100, mode=mode, call_mask=mask4[:tn], capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
+                if i >= 2:
+                    ctx.record(e4[i - 2][1])
+            torch.cuda.synchronize()
+            v = sorted(ctx.elapsed_ms(a, b) for a, b in e4)
+            return v[len(v) // 2], v[0]
+
+        rows4, base4 = [], None
+        for n in (1, 2, 4, 8):
+            med, mn = shard_ms(T4 // n)
+            base4 = med if n == 1 else base4
+            rows4.append({"n_gpus": n, "tumours_per_gpu": T4 // n, "poisson_call_ms": med, "min_ms": mn, "efficiency": base4 / n / med,
+                          "R_VC_evals_per_s_whole_job": P * T4 / (med * 1e-3)})
+        if ctx.flags(clear=True) != 0:
+            raise SystemExit("kernel flags raised in the tumour-shard projection")
+        # t(T) = a + b T through the two end points: the fixed cost of a call and what it does to the eighth
+        b4 = (rows4[0]["poisson_call_ms"] - rows4[3]["poisson_call_ms"]) / (T4 - T4 // 8)
+        a4 = rows4[3]["poisson_call_ms"] - b4 * (T4 // 8)
+        shard_proj = {"workload": CONFIGS["c4"]["name"], "records": layout, "passes_per_size": reps4, "by_n_gpus": rows4,
+                      "efficiency_at_8": rows4[3]["efficiency"], "fixed_cost_ms": a4, "ms_per_tumour": b4,
+                      "note": "ONE GPU: poisson_call (stream kernel + drain kernel, HIP events, median) over config 4's first 1024 / N tumours against the same "
+                              "call over all 1024, divided by N; every call cold (an error_estimate of this run's normals between two calls).  efficiency = "
+                              "t(1024) / N / t(1024 / N).  fixed_cost_ms / ms_per_tumour: the line through the N = 1 and N = 8 points -- the drain's latency "
+                              "chain, two launch gaps and the ramp of a launch do not shrink with the shard (DESIGN 7)"}
+        del at, mask4
+        torch.cuda.empty_cache()
     sustained = None
     if not multi and lanes is None and args.sustained > 0:
         # the headline's timed window is a few milliseconds; this is the same pass repeated for ~half a second
@@ -1267,6 +1343,8 @@ def main():
             out["other_record_layouts"] = others
         if sustained:
             out["sustained"] = sustained
+        if shard_proj:
+            out["tumour_shard_projection"] = shard_proj
         if cold:
             out["cold_hbm"] = cold
         if whole_rounds:
@@ -1289,8 +1367,8 @@ def main():
                                             "back to back after the timed region (one round serves batches_per_round batches); world_size and backend as "
                                             "torch.distributed reports them (nccl = RCCL)"}
             if tumour_shard:
-                tumour_shard["note"] = ("strong scaling of the tumour shard alone (R_VC, no exchange step): poisson_call of each rank's T / N tumours, 10 calls "
-                                        "back to back with nothing else in flight, the slowest rank's time, against the same call over all T tumours on rank "
+                tumour_shard["note"] = ("strong scaling of the tumour shard alone (R_VC, no exchange step): poisson_call of each rank's T / N tumours, median of 10 cold "
+                                        "calls (the rank's own error_estimate between two of them), the slowest rank's time, against the same call over all T tumours on rank "
                                         "0's GPU alone; unverified on more than one GPU until a SCALE run exists")
                 out["tumour_shard"] = tumour_shard
                 out["tumour_shard_efficiency"] = tumour_shard.get("efficiency")
