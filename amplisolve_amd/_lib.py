@@ -120,6 +120,7 @@ HIP_SYMBOLS = {
     "ampli_set_queue_items": (C.c_int, [vp, i64]),
     "ampli_set_poisson_tuning": (C.c_int, [vp, i32, i32]),
     "ampli_error_reduce_records": (C.c_int, [vp, C.POINTER(Records), i64, i32, f32, i32, C.POINTER(AccTable), i32, vp, vp, vp, vp, vp, vp]),
+    "ampli_error_sums_inorder": (C.c_int, [vp, C.POINTER(Records), i64, f32, i32, C.POINTER(AccTable), i32]),
     "ampli_error_reduce_records_sliced": (C.c_int, [vp, C.POINTER(Records), i64, i32, f32, i32, C.POINTER(AccTable), i32, i32, vp, vp]),
     "ampli_poisson_call_records": (C.c_int, [vp, C.POINTER(Records), i64, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp]),
     "ampli_graph_begin": (C.c_int, [vp]),

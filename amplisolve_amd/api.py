@@ -292,6 +292,11 @@ class Context:
                                                         _ptr(o.flags) if o else None))
         return out
 
+    def error_sums_inorder(self, rec: Records, P: int, acc: Acc, C_value: float = 0.002, cov: int = 100, accumulate: bool = False):
+        """acc.snt in the reference's own order of addition (ampli_error_sums_inorder): one chunk, last sample first; a cohort in several
+        chunks from its LAST chunk (accumulate=False) to its first (True).  The other planes of acc are left alone."""
+        self._check(self.lib.ampli_error_sums_inorder(self.h, C.byref(rec), P, C_value, cov, C.byref(acc.struct), int(bool(accumulate))))
+
     def error_reduce_records_sliced(self, rec: Records, P: int, acc: Acc | None, n_slices: int, sums, gm, C_value: float = 0.002, cov: int = 100,
                                     first_sample: int = 0, accumulate: bool = False, summary: bool = True):
         """The last chunk of a shard's streamed cohort: acc (+) chunk straight into the slice-major exchange buffers."""

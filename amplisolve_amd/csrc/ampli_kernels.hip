@@ -2993,6 +2993,80 @@ extern "C" int ampli_gm_merge(ampli_ctx *ctx, const ampli_acc_table *d_dst, cons
     return check_launch(ctx, "gm_merge_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// The threshold sums in the REFERENCE's own order (round 6), for cohorts outside the exactness envelope of DESIGN 4.2.
+// Inside it every partial sum of `sum = sum + X + float(RD)*float(C)` (EE:1597, 1599) is exact, so any order and association --
+// ours: sample shards, waves, chunks -- gives the reference's double.  Outside it (a coverage cut-off of a few reads with depths
+// in the millions) the double depends on the order the reference adds in: estimateThresholds walks `equal_range` of an
+// unordered_multimap (EE:1555, 1565), which libstdc++ fills so that equal keys come out in REVERSE insertion order -- the last
+// file of the visit order first, and within a file a position's later lines before its first one.  One lane per position walks
+// exactly that: samples of the chunk from last to first, extras from last to first, then the primary record; the double is
+// updated as the reference's expression associates, (sum + X) + (double)(float(RD) * float(C)).  A cohort in several chunks is
+// walked chunk by chunk from the LAST chunk to the first with the sums carried in the table (accumulate).  Only the eight sums
+// are produced: counts, depth sums (integers in a double: exact to 2^53) and the Germ_Max state do not depend on this order.
+// Speed is irrelevant (a rerun of a cohort the fast path flagged); positions are independent, so it is still one launch.
+// ---------------------------------------------------------------------------
+template <int LAY>
+__global__ __launch_bounds__(256) void error_sums_inorder_kernel(const RecView rv, const long long P, const long long E, const int n,
+                                                                 const unsigned *__restrict__ dup_off, const float C, const int cov,
+                                                                 double *__restrict__ snt, const int accumulate)
+{
+    constexpr int RB = rec_bytes_of<LAY>();
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    LaneAcc a;
+    lane_acc_init(a);
+    if (accumulate) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            a.snt[0][nt] = snt[(0 * 4 + nt) * P + p];
+            a.snt[1][nt] = snt[(1 * 4 + nt) * P + p];
+        }
+    }
+    const unsigned e0 = dup_off ? dup_off[p] : 0u, e1 = dup_off ? dup_off[p + 1] : 0u;
+    for (int t = n - 1; t >= 0; --t) {
+        for (unsigned e = e1; e > e0; --e) { // the position's later lines of this file first
+            int4 r0, r1;
+            rec_decode<LAY>(rec_load_at<LAY>(rv.ext + ((size_t)t * (size_t)rv.ext_stride + (size_t)(e - 1)) * RB), r0, r1);
+            visit_record(a, r0, r1, t, C, cov, rv.rd_ext ? rv.rd_ext[(size_t)t * (size_t)E + (e - 1)] : AMPLI_ABSENT);
+        }
+        int4 r0, r1;
+        rec_decode<LAY>(rec_load_at<LAY>(rv.base + ((size_t)t * (size_t)rv.row_stride + (size_t)p) * RB), r0, r1);
+        visit_record(a, r0, r1, t, C, cov, rv.rd ? rv.rd[(size_t)t * (size_t)P + p] : AMPLI_ABSENT);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        snt[(0 * 4 + nt) * P + p] = a.snt[0][nt];
+        snt[(1 * 4 + nt) * P + p] = a.snt[1][nt];
+    }
+}
+
+extern "C" int ampli_error_sums_inorder(ampli_ctx *ctx, const ampli_records *recs, int64_t P, float C, int32_t cov,
+                                        const ampli_acc_table *d_acc, int32_t accumulate)
+{
+    if (!ctx) return AMPLI_E_INVALID;
+    if (!recs || P <= 0 || cov < 1 || !d_acc || !acc_is_bound(d_acc) || d_acc->P != P) return fail(ctx, AMPLI_E_INVALID, "error_sums_inorder: bad argument");
+    DevCohort co;
+    { int rc = cohort_from_records(ctx, recs, P, co); if (rc) return rc; }
+    if (co.n <= 0 || !co.rv.base) return fail(ctx, AMPLI_E_INVALID, "error_sums_inorder: empty cohort");
+    if (co.E > 0 && !co.dup_off) return fail(ctx, AMPLI_E_INVALID, "error_sums_inorder: E > 0 needs dup_off");
+    {
+        const uintptr_t am = co.layout == AMPLI_RECORDS_U24 ? 7 : 15;
+        if (((uintptr_t)co.rv.base & am) != 0 || (co.E > 0 && ((uintptr_t)co.rv.ext & am) != 0))
+            return fail(ctx, AMPLI_E_INVALID, "error_sums_inorder: recs must be 16-byte aligned (8-byte for the 24-byte layout)");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const dim3 grid((unsigned)((P + 255) / 256));
+#define AMPLI_LAUNCH_INORDER(LV)                                                                                                  \
+    hipLaunchKernelGGL((error_sums_inorder_kernel<LV>), grid, dim3(256), 0, main_stream(ctx), co.rv, (long long)P, (long long)co.E, \
+                       (int)co.n, co.E > 0 ? co.dup_off : nullptr, C, (int)cov, d_acc->snt, accumulate ? 1 : 0)
+    if (co.layout == AMPLI_RECORDS_U24) AMPLI_LAUNCH_INORDER(AMPLI_RECORDS_U24);
+    else if (co.layout == AMPLI_RECORDS_U16) AMPLI_LAUNCH_INORDER(AMPLI_RECORDS_U16);
+    else AMPLI_LAUNCH_INORDER(AMPLI_RECORDS_I32);
+#undef AMPLI_LAUNCH_INORDER
+    return check_launch(ctx, "error_sums_inorder_kernel");
+}
+
 extern "C" int ampli_error_finalize(ampli_ctx *ctx, const ampli_acc_table *d_acc, float C, int32_t cov, float *d_rate,
                                     uint8_t *d_code, float *d_thr, float *d_germ_val, uint8_t *d_germ_present,
                                     int32_t *d_flags)

@@ -56,6 +56,7 @@ static void load()
     BIND(poisson_call, "ampli_poisson_call") BIND(set_tuning, "ampli_set_tuning") BIND(ctx_flags, "ampli_ctx_flags") BIND(set_queue_items, "ampli_set_queue_items")
     BIND(error_reduce_records, "ampli_error_reduce_records") BIND(poisson_call_records, "ampli_poisson_call_records") BIND(acc_to_slices, "ampli_acc_to_slices")
     BIND(error_reduce_records_sliced, "ampli_error_reduce_records_sliced") BIND(last_reduce_kernel, "ampli_last_reduce_kernel")
+    BIND(error_sums_inorder, "ampli_error_sums_inorder")
     BIND(event_create, "ampli_event_create") BIND(event_destroy, "ampli_event_destroy") BIND(event_record, "ampli_event_record") BIND(event_sync, "ampli_event_sync")
     BIND(pileup_count, "ampli_pileup_count")
     BIND(comm_create, "ampli_comm_create") BIND(comm_destroy, "ampli_comm_destroy") BIND(comm_reduce_scatter_f64, "ampli_comm_reduce_scatter_f64")

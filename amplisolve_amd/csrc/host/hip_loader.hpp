@@ -54,6 +54,7 @@ struct HipApi {
     int (*error_reduce_records_sliced)(ampli_ctx *, const ampli_records *, int64_t, int32_t, float, int32_t, const ampli_acc_table *, int32_t, int32_t,
                                        double *, float *);
     int (*last_reduce_kernel)(const ampli_ctx *);
+    int (*error_sums_inorder)(ampli_ctx *, const ampli_records *, int64_t, float, int32_t, const ampli_acc_table *, int32_t);
     int (*event_create)(void **);
     int (*event_destroy)(void *);
     int (*event_record)(ampli_ctx *, void *);

@@ -595,6 +595,7 @@ int run_error_estimation(const EeArgs &a)
             files = list_count_files(a.germline_dir, writer ? list_name : std::string());
         }
         const int total_samples = (int)files.size();
+        const std::vector<std::pair<std::string, std::string>> all_files = files; // the whole cohort in visit order (the in-order pass below)
         int first_sample = 0;
         if (sh) files = shard_of_files(files, sh->index, sh->count, &first_sample);
         const int S = (int)files.size();
@@ -745,7 +746,44 @@ int run_error_estimation(const EeArgs &a)
         dev.download(gp.data(), d_gp, gp.size());
         dev.download(&flags, d_flags, 1);
         dev.sync();
-        if (flags & 1) throw Error{AMPLI_E_ENVELOPE, "a double accumulator left the exactness envelope (see DESIGN.md); refusing to write an inexact table"};
+        if (flags & 1) {
+            // A threshold sum left the exactness envelope (a coverage cut-off of a few reads with depths in the millions): its
+            // double is no longer independent of the order of addition, and the reference always writes a table (EE:1597-1606, 1679-1704).
+            // So the sums are formed once more in the reference's OWN order -- estimateThresholds' walk of `equal_range`, which libstdc++
+            // hands out in reverse insertion order: the last file first, a position's later lines before its first -- one lane per position
+            // (ampli_error_sums_inorder).  Every chunk of the WHOLE cohort stays resident for it (the walk starts at the last chunk); the
+            // order-free planes (depth sums, counts, Germ_Max) come from an ordinary pass of the literal kernel over the same chunks.  Only
+            // the process that writes the table does this (a shard's own table was merged in another order; nobody reads it again).
+            std::cout << "\n\ta threshold sum is beyond the range in which its order of addition cannot matter: summing again in the reference's order" << std::endl;
+            if (writer) {
+                PhaseClock::Scope sc("inorder_pass");
+                dev.check(dev.api->set_tuning(dev.ctx, 0, 1, 0), "ampli_set_tuning"); // the literal kernel: every plane exact, any depth
+                need_acc();
+                ChunkStream cs(panel, all_files, threads, false, chunk_bytes_setting(), ring_slots_setting(chunk_bytes_setting()));
+                std::vector<std::unique_ptr<DevSlot>> resident;
+                std::vector<ampli_records> descr;
+                for (Chunk *c; (c = cs.next()) != nullptr;) {
+                    resident.emplace_back(new DevSlot());
+                    const ampli_records r = upload_chunk(dev, *resident.back(), *c, false);
+                    dev.check(dev.api->error_reduce_records(dev.ctx, &r, P, c->first, C_value, cov, &acc, descr.empty() ? 0 : AMPLI_REDUCE_ACCUMULATE, nullptr, nullptr,
+                                                            nullptr, nullptr, nullptr, nullptr), "ampli_error_reduce_records");
+                    dev.sync(); // the chunk's host buffer is free again; its device copy stays
+                    descr.push_back(r);
+                    cs.release(c);
+                }
+                if (descr.empty()) throw Error{AMPLI_E_INVALID, "no sample could be read from " + a.germline_dir};
+                for (size_t k = descr.size(); k-- > 0;)
+                    dev.check(dev.api->error_sums_inorder(dev.ctx, &descr[k], P, C_value, cov, &acc, k + 1 == descr.size() ? 0 : 1), "ampli_error_sums_inorder");
+                dev.check(dev.api->error_finalize(dev.ctx, &acc, C_value, cov, d_rate, d_code, nullptr, d_germ, d_gp, nullptr), "ampli_error_finalize");
+                dev.download(rate.data(), d_rate, rate.size());
+                dev.download(code.data(), d_code, code.size());
+                dev.download(germ.data(), d_germ, germ.size());
+                dev.download(gp.data(), d_gp, gp.size());
+                int32_t kf = 0;
+                dev.check(dev.api->ctx_flags(dev.ctx, &kf, 1), "ampli_ctx_flags");
+                if (kf != 0) throw Error{AMPLI_E_HIP, "the in-order pass raised kernel flags " + std::to_string(kf)};
+            }
+        }
         double t3 = now_s();
 
         char name[64];
@@ -859,6 +897,7 @@ int run_variant_calling(const VcArgs &a)
             files = list_count_files(a.tumour_dir, writer ? list_name : std::string());
         }
         const int total_samples = (int)files.size();
+        const std::vector<std::pair<std::string, std::string>> all_files = files; // the whole cohort in visit order (the in-order pass below)
         int first_sample = 0;
         if (sh) files = shard_of_files(files, sh->index, sh->count, &first_sample);
         const int T = (int)files.size();

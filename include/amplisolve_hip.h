@@ -235,6 +235,19 @@ int ampli_error_reduce_records_sliced(ampli_ctx *ctx, const ampli_records *recs,
                                       double *d_sums, float *d_gm);
 
 /*
+ * The eight threshold sums of d_acc (snt[2][4][P]) in the REFERENCE's own order of addition -- what estimateThresholds'
+ * walk of `equal_range` (EE:1555-1606) amounts to with libstdc++: the last file of the visit order first, a position's later
+ * lines of a file before its first one -- for cohorts outside the exactness envelope (ampli_error_finalize raised flag bit 0:
+ * a sum's partial sums are no longer all exact, so the double depends on the order).  recs = one chunk; a cohort in several
+ * chunks is walked from its LAST chunk (accumulate = 0) to its first (accumulate = 1).  Every other plane of d_acc is left as
+ * an ordinary ampli_error_reduce_records pass wrote it (they do not depend on the order); ampli_error_finalize on the table then
+ * gives the reference's rates (it raises flag bit 0 again: pass d_flags = NULL or ignore the bit).  One lane per position,
+ * sequential over the samples: a fallback, not a fast path.
+ */
+int ampli_error_sums_inorder(ampli_ctx *ctx, const ampli_records *recs, int64_t P, float C, int32_t coverage_cutoff,
+                             const ampli_acc_table *d_acc, int32_t accumulate);
+
+/*
  * acc_merge -- ordered combine of nparts partial tables (parts[0] = earliest
  * samples) into d_dst (may alias parts[0]).  Sums add; the germ-max triple
  * composes as the reference's sequential state machine would.  This is the

@@ -257,6 +257,37 @@ void oracle_error_reduce_rd(const int32_t *recs, const int32_t *rdcol, int64_t P
 #undef RDC
 }
 
+/* The eight threshold sums in the order the reference adds them: estimateThresholds walks `equal_range` of an
+ * unordered_multimap (EE:1555, 1565-1606) that storeGermlineStatistics filled in visit order (EE:1245 and clones), and libstdc++
+ * hands equal keys back in REVERSE insertion order -- the last file first, within a file a position's later lines before its
+ * first.  Inside the exactness envelope this equals oracle_error_reduce's snt; outside it, this is the reference's double
+ * (pinned against the compiled reference on cohorts outside the envelope: tests/test_oracle_golden.py). */
+void oracle_error_sums_inorder(const int32_t *recs, const int32_t *rdcol, int64_t P, int64_t E, const uint32_t *dup_off,
+                               int32_t S, float C, int32_t cov, double *snt)
+{
+    const int64_t R = P + E;
+#define RDC(s_, r_) (rdcol ? rdcol[(size_t)(s_) * R + (r_)] : ORACLE_ABSENT)
+    double *srd2 = (double *)calloc((size_t)(8 * P), sizeof(double));
+    int32_t *cnt2 = (int32_t *)calloc((size_t)(4 * P), sizeof(int32_t));
+    int32_t *nrec2 = (int32_t *)calloc((size_t)P, sizeof(int32_t));
+    int32_t *g1 = (int32_t *)calloc((size_t)(4 * P), sizeof(int32_t));
+    int32_t *g2 = (int32_t *)calloc((size_t)(4 * P), sizeof(int32_t));
+    float *g3 = (float *)calloc((size_t)(4 * P), sizeof(float));
+    float *g4 = (float *)calloc((size_t)(4 * P), sizeof(float));
+    for (int64_t i = 0; i < 8 * P; ++i) snt[i] = 0.0;
+    for (int64_t p = 0; p < P; ++p) {
+        for (int32_t s = S - 1; s >= 0; --s) {
+            const int32_t *base = recs + (size_t)s * R * 8;
+            if (dup_off)
+                for (uint32_t e = dup_off[p + 1]; e > dup_off[p]; --e)
+                    visit_record(base + (P + e - 1) * 8, RDC(s, P + e - 1), s, C, cov, p, P, snt, srd2, cnt2, nrec2, g1, g2, g3, g4);
+            visit_record(base + p * 8, RDC(s, p), s, C, cov, p, P, snt, srd2, cnt2, nrec2, g1, g2, g3, g4);
+        }
+    }
+    free(srd2); free(cnt2); free(nrec2); free(g1); free(g2); free(g3); free(g4);
+#undef RDC
+}
+
 /* Ordered combine of two partial tables, L covering earlier samples than R.
  * Sums add (exact inside the envelope); the germ-max state machine of
  * EE:1251-1271 composes as: the first qualifying record overall is L's if L

@@ -68,6 +68,11 @@ void oracle_error_reduce_rd(const int32_t *recs, const int32_t *rdcol, int64_t P
                             int32_t *nrec, int32_t *gm_n, int32_t *gm_first, float *gm_first_af, float *gm_rest,
                             int32_t *order_sensitive);
 
+/* snt [2][4][P] in the reference's own order of addition (reverse insertion order of its multimap: last sample first, a position's
+ * later lines before its first); equals oracle_error_reduce's snt inside the exactness envelope, IS the reference's double outside it */
+void oracle_error_sums_inorder(const int32_t *recs, const int32_t *rdcol, int64_t P, int64_t E, const uint32_t *dup_off,
+                               int32_t S, float C, int32_t cov, double *snt);
+
 /* ordered merge of two partial tables (L = earlier samples); result into L */
 void oracle_acc_merge(int64_t P, double *snt, int64_t *srd, int32_t *cnt, int32_t *nrec,
                       int32_t *gm_n, int32_t *gm_first, float *gm_first_af, float *gm_rest,

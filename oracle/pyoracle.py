@@ -89,6 +89,21 @@ def error_reduce(recs, P, C_value=0.002, cov=100, E=0, dup_off=None, first_sampl
     return out
 
 
+def error_sums_inorder(recs, P, C_value=0.002, cov=100, E=0, dup_off=None, rd=None):
+    """snt [2, 4, P] in the reference's own order of addition (oracle_error_sums_inorder): what a cohort outside the exactness
+    envelope (error_reduce(...)["order_sensitive"] == 1) gets in the reference's table"""
+    recs = np.ascontiguousarray(recs, np.int32)
+    S = recs.shape[0]
+    assert recs.size == S * (P + E) * 8
+    if rd is not None:
+        rd = np.ascontiguousarray(rd, np.int32)
+    if dup_off is not None:
+        dup_off = np.ascontiguousarray(dup_off, np.uint32)
+    snt = np.empty((2, 4, P), np.float64)
+    lib().oracle_error_sums_inorder(_p(recs), _p(rd), C.c_int64(P), C.c_int64(E), _p(dup_off), C.c_int32(S), C.c_float(C_value), C.c_int32(cov), _p(snt))
+    return snt
+
+
 def acc_merge(L, R):
     """L (+) R in place on copies; L covers the earlier samples."""
     L = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in L.items()}

@@ -17,7 +17,8 @@
 // usage: ee_ref_driver <bed> <refbases.txt> <dups.txt> <germline_dir> <C> <cov> <out_dir> [dump_prefix]
 //   writes <out_dir>/positionSpecificNoise_<C>.txt exactly as the reference does; with dump_prefix also
 //   <dump_prefix>.order (sample visit order), <dump_prefix>.counts (Count_Hash: the integer quorum
-//   counts, EE:1665) and prints per-phase wall seconds on stderr as "TIMING <phase> <seconds>".
+//   counts, EE:1665), <dump_prefix>.walk (per key the records in the order estimateThresholds adds them: its
+//   equal_range walk) and prints per-phase wall seconds on stderr as "TIMING <phase> <seconds>".
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -112,6 +113,17 @@ int main(int argc, char **argv)
             o1 << it->second << "\n"; // visit order of EE:1081
         std::ofstream o2(p + ".counts");
         for (auto it = Count_Hash.begin(); it != Count_Hash.end(); ++it) o2 << it->first << "\t" << it->second << "\n";
+        // the order estimateThresholds adds a key's records in (EE:1555, 1565: `equal_range` of the reference's own multimap, walked with
+        // the reference's own container): one line per key, the values ("Xfw_FW_Xbw_BW", EE:1236-1245) in iteration order
+        std::ofstream o3(p + ".walk");
+        for (auto a = ReferenceBase_Hash.begin(); a != ReferenceBase_Hash.end(); ++a)
+            for (const char *nt : {"A", "C", "G", "T"}) {
+                const std::string key = a->first + "_" + nt;
+                auto r = GermlineValues_Hash_forThresholds.equal_range(key);
+                o3 << key;
+                for (auto b = r.first; b != r.second; ++b) o3 << "\t" << b->second;
+                o3 << "\n";
+            }
     }
     return 0;
 }

@@ -253,3 +253,35 @@ def write_fresh_tumours(d, seed, T=4, depth=None, spike=0.06, sub="T"):
                 f.write(f"{c}\t{x}\t.\t.\t.\t.\t{tot[0]}\t{tot[1]}\t{tot[2]}\t{tot[3]}\t{tot.sum()}\t{rec[4]}\t{rec[5]}\t{rec[6]}\t{rec[7]}\n")
                 n += 1
     return n
+
+
+def write_envelope_panel(d, seed, S=9, n=120, twice=True):
+    """a panel whose threshold sums are NOT order-free at coverage_cutoff = 1: a few reads deep lines (tiny fp32 products with low bits)
+    among lines tens of millions deep with alternative counts just under 5 % (sums beyond 2^53 ulps of the tiny addends)"""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    walk = [("chr1", 1000 + i) for i in range(n)]
+    if twice:
+        walk += [("chr1", 1000 + i) for i in range(n - 20, n)]  # the last 20 positions listed twice
+    (d / "N").mkdir()
+    (d / "p.bed").write_text(f"chr1\t1000\t{1000 + n - 1}\ta\tb\tc\n" + (f"chr1\t{1000 + n - 20}\t{1000 + n - 1}\ta2\tb2\tc2\n" if twice else ""))
+    (d / "r.txt").write_text("".join(f"{c}\t{x}\tA\n" for c, x in walk))
+    (d / "d.txt").write_text("".join(f"chr1\t{1000 + i}\n" for i in range(n - 20, n)) if twice else "")
+    for s in range(S):
+        with open(d / "N" / f"E{s:02d}.PILEUP.ASEQ", "w") as f:
+            f.write("chr\tpos\tdbsnp\tMAF\tref\talt\tA\tC\tG\tT\tRD\tArs\tCrs\tGrs\tTrs\n")
+            for c, x in walk:
+                if rng.random() < 0.05:
+                    continue
+                if rng.random() < 0.35:
+                    fw, bw = int(rng.integers(1, 9)), int(rng.integers(1, 9))          # a few reads
+                    alt = [0, 0, 0]
+                    altr = [0, 0, 0]
+                else:
+                    fw, bw = int(rng.integers(20_000_000, 45_000_000)), int(rng.integers(20_000_000, 45_000_000))
+                    alt = [int(fw * rng.uniform(0.0, 0.0499)) for _ in range(3)]
+                    altr = [int(bw * rng.uniform(0.0, 0.0499)) for _ in range(3)]
+                a_f, a_r = fw - sum(alt), bw - sum(altr)
+                tot = [a_f + a_r] + [alt[i] + altr[i] for i in range(3)]
+                f.write(f"{c}\t{x}\t.\t.\t.\t.\t{tot[0]}\t{tot[1]}\t{tot[2]}\t{tot[3]}\t{sum(tot)}\t{a_r}\t{altr[0]}\t{altr[1]}\t{altr[2]}\n")
