@@ -1,4 +1,5 @@
-"""The multi-rank merge protocol (amplisolve_amd/dist.py) over gloo, world_size 2, on CPU.
+"""The multi-rank merge protocol (amplisolve_amd/dist.py) over gloo, world_size 2, 3 and 8 (the node's rank count: 23 samples and 1500
+positions divide by neither), on CPU.
 
 Each rank reduces its contiguous shard of the normal samples (here with the oracle, since there is no GPU),
 then the ranks merge exactly as bench.py does over RCCL: all-reduce SUM of the additive planes, all-gather
@@ -192,8 +193,7 @@ def sliced_worker(rank, world, port, q, slim=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("slim", [False, True])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,slim", [(2, False), (2, True), (3, False), (3, True), (8, True), (8, False)])
 def test_sliced_merge_protocol_over_gloo(world, slim):
     """Slice ownership, chunk order of the reduce-scatter / all-to-all / all-gather and the ordered germ-max fold:
     every rank ends with every slice of the single-pass error table, bit for bit -- with the sums as 21 plain planes and as the
@@ -223,7 +223,7 @@ def test_shard_range_partitions():
             assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_merge_protocol_over_gloo(world):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
