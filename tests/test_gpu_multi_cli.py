@@ -35,10 +35,11 @@ def strip_dates(text):
     return "\n".join(l for l in text.splitlines() if not l.startswith("##fileDate="))
 
 
-@pytest.mark.parametrize("world", [2, 3, 4, 5])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_error_estimation_sharded_equals_one_process(tmp_path, world):
-    """5 normal files over 2 .. 5 processes (the GPU box allows 6 processes on its card, pytest included: five ranks is the most a
-    one-GPU box can rehearse; the merge protocol itself runs with 8 ranks over gloo on the CPU, tests/test_dist_gloo.py)."""
+    """5 normal files over 2, 3 and 4 processes.  The GPU box allows 6 processes on its card: pytest's own context, the launcher
+    (torch.distributed.run opens the device too) and four ranks -- round 6 tried five and the pool's process guard ended the run.  The
+    native mode below (no launcher) goes to five; the merge protocol itself runs with 8 ranks over gloo on the CPU (tests/test_dist_gloo.py)."""
     d = f"{G}/toy_subset"
     out = tmp_path / "multi"
     torchrun(world, 29541 + world, ["AmpliSolveErrorEstimation", f"panel_design={d}/panel.bed", "reference_genome=unused.fa", f"germline_dir={d}/NORMAL",
@@ -77,9 +78,9 @@ def test_error_estimation_sharded_edge_cases(tmp_path):
     assert (out / "positionSpecificNoise_0.0005.txt").read_text() == open(f"{d}/expected_positionSpecificNoise_0.0005_cov1.txt").read()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4, 5])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_variant_calling_sharded_equals_one_process(tmp_path, world):
-    """3 tumour files (one without any call) over 2 .. 5 processes (with 4 and 5, ranks without a file): Summary and every VCF as the one-process run."""
+    """3 tumour files (one without any call) over 2, 3 and 4 processes: Summary and every VCF as the one-process run."""
     d = f"{G}/toy_subset"
     table = f"{d}/expected_positionSpecificNoise_0.0020.txt"
     one = tmp_path / "one"
