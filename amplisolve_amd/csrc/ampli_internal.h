@@ -58,6 +58,7 @@ struct ampli_ctx {
     hipEvent_t ev_stream_done = nullptr, ev_drain_done = nullptr;
     bool drain_pending = false;
     int n_cu = 256;
+    int sticky = 0; // an error met where nothing could return it (joining the position ranges inside main_stream()): reported by check_launch()
     // poisson_call tuning (ampli_set_poisson_tuning; 0 = default)
     int pc_rows_per_wave = 0, pc_drain_blocks = 0;
     // kf_lgamma at the integers 0 .. AMPLI_LGTAB - 1, filled by the device's own ampli_kf_lgamma (the all-scores mode's scorer)
@@ -86,6 +87,11 @@ static inline int check_launch(ampli_ctx *ctx, const char *what)
     if (e != hipSuccess) {
         ctx->err = std::string(what) + ": " + hipGetErrorString(e);
         return AMPLI_E_HIP;
+    }
+    if (ctx->sticky) { // ctx->err says what it was
+        const int rc = ctx->sticky;
+        ctx->sticky = 0;
+        return rc;
     }
     return AMPLI_OK;
 }

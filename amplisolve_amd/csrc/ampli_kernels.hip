@@ -174,12 +174,21 @@ static inline hipStream_t lane_stream(ampli_ctx *ctx, const int k) { return ctx-
 int ampli_ranges_join_internal(ampli_ctx *ctx)
 {
     if (!ctx->ranges_open) return AMPLI_OK;
-    ctx->ranges_open = false;
+    // Every lane is joined whatever happens to another: a lane whose event cannot be recorded or waited for is waited for on the
+    // host instead, and only a lane that cannot be joined at all leaves an error -- a sticky one (main_stream() has no way to return
+    // it), which the entry point that asked for the stream reports from check_launch().  The section counts as closed only then.
+    int rc = AMPLI_OK;
     for (int k = 0; k < ctx->n_ranges; ++k) {
-        HIP_TRY(ctx, hipEventRecord(ctx->lanes[k].done, ctx->lanes[k].stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->lanes[k].done, 0));
+        hipError_t e = hipEventRecord(ctx->lanes[k].done, ctx->lanes[k].stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->lanes[k].done, 0);
+        if (e != hipSuccess) e = hipStreamSynchronize(ctx->lanes[k].stream);
+        if (e != hipSuccess) {
+            ctx->err = std::string("joining position range ") + std::to_string(k) + ": " + hipGetErrorString(e);
+            ctx->sticky = rc = AMPLI_E_HIP;
+        }
     }
-    return AMPLI_OK;
+    ctx->ranges_open = false;
+    return rc;
 }
 
 // open the section for a panel of P positions (or keep it open if it is cut for the same panel)
@@ -1266,7 +1275,7 @@ __global__ __launch_bounds__(256) void error_reduce_kernel(
 // ---------------------------------------------------------------------------
 struct Fast16 {
     int sx[2][4];
-    int sd[2][4];
+    unsigned sd[2][4]; // unsigned: 1023 records of 24-bit strand depths below 2^22 reach 2^32 - 2^22, beyond INT_MAX (a signed sum would be undefined there)
     double sp[2][4];
     unsigned cnt01, cnt23; // cnt[0] | cnt[1] << 16, cnt[2] | cnt[3] << 16
     float gfa[4];          // AF of the first qualifying record (EE:1229-1232); its value is dropped by the reference (EE:1258-1261)
@@ -1324,8 +1333,8 @@ __device__ __forceinline__ void visit16(Fast16 &a, const int4 r0, const int4 r1,
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         if (__builtin_amdgcn_inverse_ballot_w64(thrmask[nt])) {
-            a.sx[0][nt] += fw[nt]; a.sd[0][nt] += FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
-            a.sx[1][nt] += bw[nt]; a.sd[1][nt] += BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
+            a.sx[0][nt] += fw[nt]; a.sd[0][nt] += (unsigned)FW; a.sp[0][nt] += prod_fw; // EE:1597-1598
+            a.sx[1][nt] += bw[nt]; a.sd[1][nt] += (unsigned)BW; a.sp[1][nt] += prod_bw; // EE:1599-1600
             if (nt < 2) a.cnt01 += nt == 0 ? 1u : 65536u;                     // EE:1606
             else a.cnt23 += nt == 2 ? 1u : 65536u;
         }
@@ -1482,7 +1491,7 @@ __device__ __forceinline__ void compact_reduce_body(Red16Shared &sh, const RecVi
     Fast16 f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        f.sx[0][nt] = f.sx[1][nt] = 0; f.sd[0][nt] = f.sd[1][nt] = 0; f.sp[0][nt] = f.sp[1][nt] = 0.0;
+        f.sx[0][nt] = f.sx[1][nt] = 0; f.sd[0][nt] = f.sd[1][nt] = 0u; f.sp[0][nt] = f.sp[1][nt] = 0.0;
         f.gfa[nt] = 0.0f; f.gbx[nt] = 0; f.gbd[nt] = 1; f.zmask[nt] = ~0ull; f.lmask[nt] = 0ull;
     }
     f.cnt01 = f.cnt23 = 0u;
@@ -1530,7 +1539,7 @@ __device__ __forceinline__ void compact_reduce_body(Red16Shared &sh, const RecVi
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             a.snt[st][nt] = (double)f.sx[st][nt] + f.sp[st][nt];
-            a.srd[st][nt] = (long long)(unsigned)f.sd[st][nt];
+            a.srd[st][nt] = (long long)f.sd[st][nt];
         }
         // qualifying records of the chunk, saturated at two: every reader asks "none, one, or more" (lane_acc_merge's sums keep that)
         const bool none = (f.zmask[nt] >> lane) & 1, later = (f.lmask[nt] >> lane) & 1;

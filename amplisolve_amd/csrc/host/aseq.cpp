@@ -584,8 +584,14 @@ void Chunk::pin(ampli_ctx *ctx)
     const HipApi *api = hip_api();
     if (!api) return;
     PhaseClock::Scope sc("host_register");
-    if (prim && !prim_pinned && api->host_register(ctx, prim, prim_cap) == AMPLI_OK) prim_pinned = true;
-    if (ext && !ext_pinned && api->host_register(ctx, ext, ext_cap) == AMPLI_OK) ext_pinned = true;
+    bool refused = false;
+    if (prim && !prim_pinned) { if (api->host_register(ctx, prim, prim_cap) == AMPLI_OK) prim_pinned = true; else refused = true; }
+    if (ext && !ext_pinned) { if (api->host_register(ctx, ext, ext_cap) == AMPLI_OK) ext_pinned = true; else refused = true; }
+    if (refused) { // the upload still works (the runtime stages it), only slower: say so once instead of degrading in silence
+        static std::once_flag once;
+        std::call_once(once, [&] { std::cerr << "note: a record buffer of " << (prim_cap >> 20) << " MB could not be pinned (hipHostRegister refused: locked-memory limit?); "
+                                                "its uploads are staged by the runtime" << std::endl; });
+    }
 }
 
 struct ChunkStream::Impl {
@@ -601,6 +607,8 @@ struct ChunkStream::Impl {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<int> free_slots, ready; // ready: slot indices in chunk order
+    size_t ring_budget = 0;             // bytes the slots in circulation may hold: the ring as it was sized (in the narrowest layout allowed)
+    int outstanding = 0;                // chunks handed to the consumer and not released yet
     bool done = false, stop = false, failed = false;
     Error err{0, ""};
     std::thread producer;
@@ -707,7 +715,17 @@ struct ChunkStream::Impl {
                 int slot;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || !free_slots.empty(); });
+                    // The ring was sized in the narrowest layout the packer may use.  Once the cohort has turned out to need wider records
+                    // (24 or 32 bytes each) every slot that is refilled grows by half or doubles -- and is pinned: with the default 16 slots of
+                    // 128 MB that was 3-4 GiB of locked memory for an int32 cohort.  So the number of slots in circulation shrinks with the
+                    // layout in use (at least four stay: what the pipeline needs to keep the parsers ahead of the uploads).
+                    auto may_take = [&] {
+                        if (free_slots.empty()) return false;
+                        const size_t slot_bytes = (size_t)per_chunk * (size_t)panel.P() * record_bytes(start_layout);
+                        const size_t max_live = std::max<size_t>(4, ring_budget / std::max<size_t>(1, slot_bytes));
+                        return slots.size() - free_slots.size() < max_live;
+                    };
+                    cv.wait(lk, [&] { return stop || may_take(); });
                     if (stop) return;
                     slot = free_slots.back();
                     free_slots.pop_back();
@@ -773,6 +791,7 @@ ChunkStream::ChunkStream(const Panel &panel, std::vector<std::pair<std::string, 
         c->prim_cap = (size_t)per * (size_t)P * record_bytes(im->start_layout); // a chunk that needs wider records grows its buffer (fill)
         c->prim = ring_alloc(c->prim_cap);
         if (!c->prim) throw Error{AMPLI_E_NOMEM, "cannot allocate the record buffers"};
+        im->ring_budget += c->prim_cap;
         im->slots.push_back(std::move(c));
         im->free_slots.push_back(i);
     }
@@ -826,8 +845,12 @@ Chunk *ChunkStream::next()
         if (im->failed) throw im->err;
         return nullptr;
     }
+    // The consumers map ring slot k to device buffer k mod kDevSlots (pipeline.cpp) and that is only safe because a chunk is uploaded,
+    // consumed and waited for before the next one is taken: checked here rather than assumed.
+    if (im->outstanding != 0) throw Error{AMPLI_E_INVALID, "ChunkStream::next(): the previous chunk was not released (its device buffers would be overwritten)"};
     const int slot = im->ready.front();
     im->ready.erase(im->ready.begin());
+    im->outstanding = 1;
     return im->slots[(size_t)slot].get();
 }
 
@@ -836,6 +859,7 @@ void ChunkStream::release(Chunk *c)
     {
         std::lock_guard<std::mutex> lk(im->mu);
         im->free_slots.push_back(c->slot);
+        im->outstanding = 0;
     }
     im->cv.notify_all();
 }

@@ -223,3 +223,79 @@ def test_streamed_chunks_over_position_ranges(ctx):
             ctx.set_tuning(0)
         _summary_equal(acc, ref)
         assert_final_equal(fin, orc.error_finalize(ref))
+
+
+def test_u24_strand_depth_sums_beyond_2_to_31_per_lane(ctx):
+    """a lane of error_reduce_u24_kernel takes up to 1023 records whose strand depths lie just under 2^22, so its 32-bit depth
+    sums pass INT_MAX and reach towards 2^32: kept unsigned and widened at the end.  Same table as the oracle, no rerun flag."""
+    rng = np.random.default_rng(2)
+    P, S = 130, 2400  # four waves of 600 records: 600 x 4.19e6 = 2.5e9 > 2^31 per lane and strand
+    recs = np.zeros((S, P, 8), np.int32)
+    fwd = rng.random(P) < 0.5  # which strand carries the depth at this position (RD = FW + BW stays below 2^22)
+    big = rng.integers(4_190_000, 4_194_000, (S, P))
+    small = rng.integers(100, 300, (S, P))
+    FW = np.where(fwd[None, :], big, small)
+    BW = np.where(fwd[None, :], small, big)
+    for st, depth in ((0, FW), (4, BW)):
+        alts = (depth[:, :, None] * rng.uniform(0, 0.012, (S, P, 3))).astype(np.int64)
+        recs[:, :, st + 1: st + 4] = alts
+        recs[:, :, st] = depth - alts.sum(-1)
+    assert int((recs[:, :, :4].sum(-1) + recs[:, :, 4:].sum(-1)).max()) < (1 << 22)
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    assert int(ref["srd"].max()) > (1 << 31) * 4 and ref["order_sensitive"] == 0
+    want = orc.error_finalize(ref)
+    ctx.set_record_layout("u24")
+    try:
+        packed = _pack(ctx, recs, "u24")
+        ctx.set_reduce_compact(True)
+        ctx.set_tuning(1, groups=1)
+        got = ctx.error_estimate(packed, P, 0.002, 100)
+        assert ctx.flags() == 0 and ctx.last_reduce_kernel() == COMPACT["u24"]
+        assert_final_equal(got, want)
+        acc = ctx.new_acc(P)
+        ctx.set_reduce_compact(False)
+        ctx.set_tuning(0, groups=0)
+        fin = ctx.error_estimate(packed, P, 0.002, 100, acc=acc)
+        assert_acc_equal(acc, ref)
+        assert_final_equal(fin, want)
+    finally:
+        ctx.set_reduce_compact(True)
+        ctx.set_tuning()
+        ctx.set_record_layout("i32")
+
+
+@pytest.mark.parametrize("where", ["first", "middle", "last"])
+def test_u24_depth_between_2_to_22_and_2_to_24_raises_the_rerun_flag(ctx, where):
+    """a covered 24-bit record with RD in [2^22, 2^24) is packable (so the compact 24-bit kernel is chosen) but outside the
+    fast arithmetic: the kernel's only guard is its DEPTH_CHECK bit -> AMPLI_FLAG_RERUN_GENERAL, in whichever chunk of a streamed
+    cohort the record sits (the table written by the earlier chunks is then void and the literal kernel redoes the cohort)."""
+    rng = np.random.default_rng(11)
+    P, S = 300, 12
+    recs = synth_recs(P, S, depth=3000)
+    s_deep = {"first": 1, "middle": 6, "last": 11}[where]
+    deep = 6_000_000  # 2^22 < RD = 12e6 < 2^24
+    recs[s_deep, 77] = [deep - 30, 10, 10, 10, deep - 30, 10, 10, 10]
+    ref = orc.error_reduce(recs, P, 0.002, 100)
+    want = orc.error_finalize(ref)
+    ctx.set_record_layout("u24")
+    try:
+        ctx.set_reduce_compact(True)
+        ctx.set_tuning(1, groups=1)
+        acc = ctx.new_acc(P)
+        cuts = (0, 4, 8, 12)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            rec = ctx.records(_pack(ctx, np.ascontiguousarray(recs[lo:hi]), "u24"), "u24", hi - lo)
+            fin = ctx.error_reduce_records(rec, P, acc, 0.002, 100, first_sample=lo, accumulate=lo > 0, summary=True, finalize=hi == 12)
+            assert ctx.last_reduce_kernel() == COMPACT["u24"]
+        assert ctx.flags() & 2  # AMPLI_FLAG_RERUN_GENERAL
+        ctx.set_tuning(0, general=True)
+        acc2 = ctx.new_acc(P)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            rec = ctx.records(_pack(ctx, np.ascontiguousarray(recs[lo:hi]), "u24"), "u24", hi - lo)
+            fin = ctx.error_reduce_records(rec, P, acc2, 0.002, 100, first_sample=lo, accumulate=lo > 0, finalize=hi == 12)
+        assert ctx.flags() == 0
+        assert_acc_equal(acc2, ref)
+        assert_final_equal(fin, want)
+    finally:
+        ctx.set_tuning()
+        ctx.set_record_layout("i32")
