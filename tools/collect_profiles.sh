@@ -3,7 +3,7 @@
 # the CPU baseline and end-to-end legs are switched off).  Outputs under gpurun_out/prof_<round>/ (ROUND, default r05) (merged back by gpurun);
 # tools/make_profile_summary.py turns them into the files committed under profiles/<round>/.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$R/gpurun_out/prof_${ROUND:-r05}
+OUT=$R/gpurun_out/prof_${ROUND:-r06}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --sustained 0 --cold-batches 0 --whole-rounds 0 --no-split-ranges"

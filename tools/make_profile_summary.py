@@ -2,7 +2,7 @@
 """Turn gpurun_out/prof_final/ (tools/collect_profiles.sh) into the committed summaries under profiles/<round>/."""
 import collections, csv, glob, json, os, shutil, sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{rnd}"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
