@@ -101,8 +101,27 @@ def main():
             d_dup = t(dup_off) if E else None
             o_acc = orc.error_reduce(recs, P, C_value, cov, E=E, dup_off=dup_off if E else None)
             o_fin = orc.error_finalize(o_acc)
+            def check_inorder():
+                """round 6: the eight threshold sums in the reference's own order of addition (ampli_error_sums_inorder), the cohort cut into
+                random chunks walked from the last to the first -- bit for bit the oracle's, inside the exactness envelope and outside it"""
+                want = orc.error_sums_inorder(recs, P, C_value, cov, E=E, dup_off=dup_off if E else None)
+                ncut = int(rng.integers(1, min(S, 4) + 1))
+                cuts = [0] + sorted(rng.choice(np.arange(1, S), size=ncut - 1, replace=False).tolist()) + [S] if ncut > 1 else [0, S]
+                acc_io = ctx.new_acc(P)
+                acc_io.buf.fill_(0x33)
+                for k in range(len(cuts) - 2, -1, -1):
+                    rec_k = ctx.records(dev[cuts[k]:cuts[k + 1]], layout, cuts[k + 1] - cuts[k], E=E, row_stride=P + E, dup_off=d_dup)
+                    ctx.error_sums_inorder(rec_k, P, acc_io, C_value, cov, accumulate=k != len(cuts) - 2)
+                if not eq_bits(acc_io.snt.cpu().numpy(), want):
+                    raise AssertionError("in-order threshold sums differ from the oracle's")
+                n["inorder"] = n.get("inorder", 0) + 1
+
             if o_acc["order_sensitive"]:
-                continue  # outside the exactness envelope by construction (tiny C, cov 1): the flag is tested elsewhere
+                check_inorder()  # outside the exactness envelope by construction (tiny C, cov 1): only the reference's own order is defined
+                n["inorder_outside_envelope"] = n.get("inorder_outside_envelope", 0) + 1
+                continue
+            if rng.random() < 0.15:
+                check_inorder()
             # ---- reduce variants ----
             general = bool(rng.random() < 0.3)
             groups = int(rng.choice([0, 1, 2, 4]))
