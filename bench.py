@@ -1251,7 +1251,9 @@ def main():
         # this same command (tools/collect_profiles.sh) and corrected as MI355X_MICROARCH.md prescribes; committed
         # under profiles/.  null when the workload is not the profiled one.
         traffic, traffic_src = None, None
-        pj = next((p for p in (os.path.join(ROOT, "profiles", r, "pmc_summary.json") for r in ("r05", "r04", "r03", "r02")) if os.path.exists(p)), "")
+        import glob
+
+        pj = next(iter(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_summary.json")), reverse=True)), "")  # the latest round's
         if args.config == "c3" and not multi and os.path.exists(pj):
             try:
                 pm = json.load(open(pj))
