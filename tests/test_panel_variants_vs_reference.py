@@ -50,7 +50,9 @@ def _vary(d, rng, what, sub="N"):
             for e in extra:
                 lines.insert(int(rng.integers(0, len(lines) + 1)), e)
         if "aseq_triple" in what and k == 1:
-            lines += [lines[3], lines[3].replace("\t5", "\t6", 1), lines[10]]  # lines 3 and 10 again: listed three times / twice
+            tok = lines[3].split("\t")
+            tok[6], tok[10] = str(int(tok[6]) + 1000), str(int(tok[10]) + 1000)  # 1000 more forward A reads (total and RD columns): a well-formed other line
+            lines += [lines[3], "\t".join(tok), lines[10]]  # lines 3 and 10 again: listed three times / twice
         if "aseq_own_rd" in what:  # lines whose RD column is not A+C+G+T (EE:1178-1181: used with their own RD, EE:1229), some of them 0
             for i in range(len(lines)):
                 if rng.random() < 0.04:

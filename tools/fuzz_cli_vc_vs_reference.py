@@ -118,7 +118,8 @@ def one_case(seed, keep=None):
                         msg.append("dummyVCF_1.vcf differs")
             ok = not msg
         else:
-            msg.append(f"rc reference {ref.returncode} ours {off.returncode}/{on.returncode}: " + (off.stdout + off.stderr)[-400:])
+            why = [ln.strip() for ln in (off.stdout + on.stdout).splitlines() if "went wrong" in ln.lower() or "error" in ln.lower()]
+            msg.append(f"rc reference {ref.returncode} ours {off.returncode}/{on.returncode}: " + ("; ".join(why)[:600] or (off.stdout + off.stderr)[-400:]))
         if not ok and keep:
             subprocess.run(["cp", "-r", str(d), keep])
         line = (f"seed {seed}: depth {depth:>7} S {S:2d} T {T} lines {lines:5d} C {C:>6} cov {cov:>4} p {pv:>4} threads {env['AMPLISOLVE_THREADS']} "
