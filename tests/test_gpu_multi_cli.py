@@ -362,3 +362,27 @@ def test_native_launcher_ends_the_job_when_one_shard_fails(tmp_path, fake_rccl):
     assert "stopping the others" in r.stderr
     assert time.time() - t0 < 120
     assert not [n for n in os.listdir(tmp_path) if n.startswith("amplisolve_rccl_id.")]
+
+
+def test_native_mode_cohort_outside_the_exactness_envelope(tmp_path, fake_rccl):
+    """Three ranks on a cohort whose threshold sums depend on the order of addition (coverage cut-off 1, depths of tens of millions):
+    the merged sums raise the envelope flag on every rank, the WRITER alone streams the whole cohort again in the reference's own order
+     while the others wait at the barrier, and the table is the reference's, byte for byte."""
+    from oracle import pyoracle as orc
+    from tests.helpers import write_envelope_panel
+
+    if not os.path.exists(orc.REF_EE_DRIVER):
+        pytest.skip("oracle/_ref/ee_ref_driver is absent")
+    d = tmp_path / "panel"
+    d.mkdir()
+    write_envelope_panel(d, 5, S=11)
+    (d / "o").mkdir()
+    r = subprocess.run([orc.REF_EE_DRIVER, "p.bed", "r.txt", "d.txt", "N", "0.002", "1", "o"], capture_output=True, text=True, cwd=d)
+    assert r.returncode == 0, r.stderr[-400:]
+    name = [n for n in os.listdir(d / "o") if n.startswith("positionSpecificNoise_")][0]
+    out = tmp_path / "native"
+    outs = native_run(3, "AmpliSolveErrorEstimation", [f"panel_design={d}/p.bed", "reference_genome=unused.fa", f"germline_dir={d}/N", "C_value=0.002",
+                                                      "coverage_cutoff=1", "default_error=0.01"], out, fake_rccl,
+                      env={"AMPLISOLVE_REFBASES_FILE": f"{d}/r.txt", "AMPLISOLVE_LIST_DIR_AS": "N", "AMPLISOLVE_CHUNK_BYTES": "40000"})
+    assert all("summing again in the reference's order" in o for o in outs)
+    assert (out / name).read_bytes() == (d / "o" / name).read_bytes()
