@@ -2326,7 +2326,8 @@ __global__ __launch_bounds__(256, 7) void poisson_stream_kernel(
 __global__ __launch_bounds__(256) void poisson_drain_kernel(
     const PcItem *__restrict__ queue, const long long queue_per_shard, const unsigned long long *__restrict__ queue_n,
     const long long R, unsigned *__restrict__ mask_words, ampli_call *__restrict__ calls, const long long capacity,
-    unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n, const unsigned shard_lo, const unsigned shard_n)
+    unsigned long long *__restrict__ n_calls, unsigned long long *__restrict__ next_queue_n, const unsigned shard_lo, const unsigned shard_n,
+    const double *__restrict__ lgtab)
 {
     constexpr int IPB = 128; // items per workgroup pass
     // the counter array of the NEXT poisson_call (the other half of a double buffer; its last reader, the previous
@@ -2354,7 +2355,7 @@ __global__ __launch_bounds__(256) void poisson_drain_kernel(
         const bool eval = on && !isinf(err) && (double)k > m; // then z = m < s = k: the series branch of kf_gammaq (VC:3728)
         double qv = -1.0; // "no call" (any value below 5)
         if (eval) {
-            if (m > 0) qv = ampli_q_from_p(1 - (1. - ampli_kf_gammap_series_nodiv((double)k, m))); // VC:3865 on top of VC:3728: p = 1 - (1 - P(s, z))
+            if (m > 0) qv = ampli_q_from_p(ampli_drain_p(k, m, lgtab, AMPLI_LGTAB)); // VC:3865 on top of VC:3728: p = 1 - (1 - P(s, z))
             else if (m == 0) qv = 100.0; // z = 0: the reference's series gives P = exp(-inf) = 0, p = 0 < 1e-10
             // m < 0 (a negative error cell, or an irregular line with RD < RD_reverse): log(z) is NaN in the reference,
             // Q is NaN and VC:898 is false
@@ -3184,7 +3185,8 @@ static int poisson_prefilter_launch(ampli_ctx *ctx, const int lane_k, hipStream_
     const unsigned dgy = (unsigned)(ctx->pc_drain_blocks > 0 ? ctx->pc_drain_blocks
                                                              : std::min<long long>(1024, std::max<long long>(16, (long long)T * Rk / 300000)));
     hipLaunchKernelGGL(poisson_drain_kernel, dim3(AMPLI_CALL_SHARDS, dgy), dim3(256), 0, dstream, (const PcItem *)Q.items, per, qn,
-                       (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next, shard_lo, shard_n);
+                       (long long)R, (unsigned *)d_call_mask, d_calls, (long long)capacity, d_n_calls, qn_next, shard_lo, shard_n,
+                       (const double *)ctx->d_lgtab);
     if (ctx->async_drain) {
         HIP_TRY(ctx, hipEventRecord(ctx->ev_drain_done, ctx->side));
         ctx->drain_pending = true;
@@ -3249,6 +3251,8 @@ static int poisson_call_impl(ampli_ctx *ctx, const DevCohort &co, int64_t P, con
     } else {
         if (((uintptr_t)d_call_mask & 3) != 0) return fail(ctx, AMPLI_E_INVALID, "poisson_call: call_mask must be 4-byte aligned");
         if (ctx->async_drain && is_capturing(ctx)) return fail(ctx, AMPLI_E_INVALID, "asynchronous drain cannot be captured");
+        // the drain's scorer reads kf_lgamma at the integers from the table: built once, on the context's stream, BEFORE any range forks
+        { int rcl = ensure_lgtab(ctx); if (rcl) return rcl; }
         // position ranges on concurrent streams (ampli_set_ranges): every range behind its own error_estimate.  Only the listed-once
         // shape: an extra occurrence reads the thresholds of a position that may belong to another range
         const bool ranged = ranges_apply(ctx, R) && E == 0 && (R & 3) == 0 && !ctx->async_drain;

@@ -43,7 +43,7 @@ extern "C" void ampli_host_drain_score_batch(const int32_t *k, const int32_t *rd
 {
     for (int64_t i = 0; i < n; ++i) {
         const double m = (double)rd[i] * err[i];
-        const double pv = 1 - (1. - ampli_kf_gammap_series_nodiv((double)k[i], m));
+        const double pv = ampli_drain_p(k[i], m, nullptr, 0); // no table on the host: the same values from the function itself
         if (p) p[i] = pv;
         if (q) q[i] = ampli_q_from_p(pv);
     }

@@ -140,9 +140,11 @@ def test_af_limit_as_one_float_multiply_is_the_integer_limit_for_every_depth():
 
 def test_division_free_series_of_the_drain_kernel_is_the_reference_series():
     """The drain kernel scores queued items (k > m) with the series of VC:3785-3794 rewritten without divisions and
-    without the early exit.  Against the oracle's literal scorer: p within 1e-9 relative everywhere (the contract is
-    1e-6), the Q = 100 / Q >= 5 / Q >= 20 decisions identical on every point -- including z so close to s that the
-    reference's 99-term cap truncates the series, and depths up to the int32 range."""
+    without the early exit -- since round 6 with kf_lgamma(k + 1) from the table of its own values and the prefactor multiplied
+    by the sum instead of adding its logarithm (ampli_drain_p: a third fewer instructions on the drain's critical path).
+    Against the oracle's literal scorer: p within 1e-11 relative everywhere (the contract is 1e-6), the Q = 100 / Q >= 5 /
+    Q >= 20 decisions identical outside 1e-9 of a gate (a pair within 1e-6 of the call gate is re-decided by the host either
+    way) -- including z so close to s that the reference's 99-term cap truncates the series, and depths up to the int32 range."""
     H = host_lib()
     rng = np.random.default_rng(8)
     ks, rds, es = [], [], []
@@ -167,10 +169,11 @@ def test_division_free_series_of_the_drain_kernel_is_the_reference_series():
     qo, po = orc.score_batch(k, rd, e)
     assert k.size > 200_000
     # p = 1 - (1 - P) is a multiple of 2^-53: a last-bit difference in P can move it by one such step
-    excess = np.abs(p - po) - (1e-12 * po + 2.3e-16)
+    excess = np.abs(p - po) - (1e-11 * po + 2.3e-16)
     assert np.max(excess) <= 0, (np.argmax(excess), np.max(excess))
     for thr in (5.0, 20.0, 100.0):
-        assert np.array_equal(q >= thr, qo >= thr), thr
+        away = np.abs(qo - thr) > 1e-9
+        assert np.array_equal((q >= thr)[away], (qo >= thr)[away]), thr
     fin = qo < 100
     assert np.max(np.abs(q[fin] - qo[fin])) < 1e-7
 

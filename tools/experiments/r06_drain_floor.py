@@ -21,7 +21,9 @@ fin = ctx.error_estimate(normals, P, 0.002, 100)
 evict = ctx.error_estimate(normals, P, 0.002, 100)
 high = torch.full_like(fin.thr, 0.5)
 res = ctx.poisson_call(tum, P, fin.thr, refc, 100, capacity=1 << 20)
-for rnd in range(3):
+DRAINS = [int(x) for x in os.environ.get("DF_DRAIN", "0").split(",")]  # drain workgroups per queue shard (0 = the default: 32 for config 3)
+for rnd, drain_blocks in [(r, d) for d in DRAINS for r in range(3 if len(DRAINS) == 1 else 2)]:
+    ctx.set_poisson_tuning(0, drain_blocks)
     for name, thr in (("real thresholds", fin.thr), ("empty queue    ", high)):
         reps = 40
         evs = [[ctx.event(), ctx.event()] for _ in range(reps)]
@@ -34,5 +36,5 @@ for rnd in range(3):
                 ctx.record(evs[i - 2][1])
         torch.cuda.synchronize()
         v = sorted(ctx.elapsed_ms(a, b) for a, b in evs)
-        print(f"round {rnd} {name}: poisson_call median {v[reps // 2] * 1e3:6.1f} us  min {v[0] * 1e3:6.1f}   calls {ctx.n_calls_total(res)}", flush=True)
+        print(f"round {rnd} drain workgroups per shard {drain_blocks:3d} {name}: poisson_call median {v[reps // 2] * 1e3:6.1f} us  min {v[0] * 1e3:6.1f}   calls {ctx.n_calls_total(res)}", flush=True)
 ctx.close()
