@@ -64,7 +64,10 @@ struct ampli_ctx {
     // kf_lgamma at the integers 0 .. AMPLI_LGTAB - 1, filled by the device's own ampli_kf_lgamma (the all-scores mode's scorer)
     double *d_lgtab = nullptr;
 };
-constexpr int AMPLI_LGTAB = 4096;
+// 65537 entries (512 KB, L2-resident): every count a uint16 record can hold, + 1 for the drain's kf_lgamma(k + 1).  (4096 until round 6:
+// a wave of the drain in which ONE lane carries a count beyond the table -- a heterozygous site at 10 000 x -- runs the Lanczos form, 8
+// divisions and 2 logarithms, for all of its lanes.)
+constexpr int AMPLI_LGTAB = 65537;
 
 #define HIP_TRY(ctx, expr)                                                                        \
     do {                                                                                          \
