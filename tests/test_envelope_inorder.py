@@ -130,10 +130,17 @@ def test_kernel_sums_equal_the_oracles_bit_for_bit(ctx, layout, deep, cuts):
 
 @need_ref
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,C,cov,S,chunk", [(1, "0.002", "1", 9, None), (2, "0.0005", "1", 14, "1"), (3, "0.03", "2", 30, "40000")])
-def test_command_line_writes_the_references_table_instead_of_refusing(tmp_path, seed, C, cov, S, chunk):
+@pytest.mark.parametrize("seed,C,cov,S,chunk,shape", [(1, "0.002", "1", 9, None, ()), (2, "0.0005", "1", 14, "1", ()), (3, "0.03", "2", 30, "40000", ()),
+                                                      (4, "0.002", "1", 12, "30000", ("aseq_own_rd", "aseq_triple", "aseq_shuffled", "aseq_header_only"))])
+def test_command_line_writes_the_references_table_instead_of_refusing(tmp_path, seed, C, cov, S, chunk, shape):
+    """... also with lines that carry their own RD column (the RD plane travels with every resident chunk of the in-order pass), a position
+    listed three times, shuffled lines and a header-only file."""
     d = tmp_path
     write_envelope_panel(d, seed, S=S)
+    if shape:
+        from tests.test_panel_variants_vs_reference import _vary
+
+        _vary(d, np.random.default_rng(seed), shape)
     want, name = _reference(d, C, cov)
     env = dict(os.environ, AMPLISOLVE_STRICT_EXIT="1", AMPLISOLVE_REFBASES_FILE="r.txt")
     if chunk:
