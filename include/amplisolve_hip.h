@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define AMPLI_ABI_VERSION 4
+#define AMPLI_ABI_VERSION 5
 #define AMPLI_ABSENT INT32_MIN
 /* record layouts, same field order in all of them:
  *   AMPLI_RECORDS_I32  int32 recs[n_samples][R][8], 32 B per record, absent: recs[..][0] == INT32_MIN

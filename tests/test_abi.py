@@ -33,7 +33,7 @@ def test_host_header_symbols_exported():
 
 def test_abi_version_and_strerror():
     lib = _lib.hip_lib()
-    assert lib.ampli_abi_version() == 4  # AMPLI_ABI_VERSION
+    assert lib.ampli_abi_version() == 5  # AMPLI_ABI_VERSION (5: ampli_error_sums_inorder, round 6)
     assert lib.ampli_strerror(0) == b"ok"
     assert b"HIP" in lib.ampli_strerror(-2)
 
