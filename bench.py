@@ -1154,15 +1154,24 @@ def main():
             red1 = sum(ctx.elapsed_ms(e[0], e[1]) for e in ev1) / args.steps
             call1 = sum(ctx.elapsed_ms(e[1], e[2]) for e in ev1) / args.steps
             rb1, cb1 = rec_bytes * P * S + 88 * P, rec_bytes * P * T + 33 * P + P * T
+            # the same passes once more with two events in all: what the one-stream pass costs when nobody times its kernels
+            ea1, eb1 = ctx.event(), ctx.event()
+            ctx.record(ea1)
+            for _ in range(args.steps):
+                local_step()
+            ctx.record(eb1)
+            torch.cuda.synchronize()
+            ms1_plain = ctx.elapsed_ms(ea1, eb1) / args.steps
             same1 = (torch.equal(ranged_out[0].view(torch.int32), f1.thr.view(torch.int32)) and torch.equal(ranged_out[1], f1.code) and
                      torch.equal(ranged_out[2], f1.germ_present) and torch.equal(ranged_out[3], call_mask) and
                      ranged_out[4] == int(n_calls[::CALL_COUNTER_STRIDE].sum().item()))
             del ranged_out
             one_stream = {"steps": args.steps, "ms_per_step": ms1, "same_outputs_as_the_timed_region": bool(same1), "value": (P * S + P * T) / (ms1 * 1e-3), "kernel": ctx.last_reduce_kernel(),
+                          "ms_per_step_without_kernel_events": ms1_plain, "value_without_kernel_events": (P * S + P * T) / (ms1_plain * 1e-3),
                           "error_reduce_ms": red1, "error_reduce_frac_of_peak": rb1 / (red1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "poisson_call_ms": call1, "poisson_call_frac_of_peak": cb1 / (call1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "note": "the pass of the timed region without position ranges (ampli_set_ranges(1)): whole launches on one stream, HIP events around "
-                                  "every kernel of every pass (the events cost a few us per pass); after the timed region"}
+                                  "every kernel of every pass (the events cost a few us per pass: ms_per_step_without_kernel_events = the same passes with two events in all); after the timed region"}
             if ctx.flags(clear=True) != 0:
                 raise SystemExit("kernel flags raised in the one-stream block")
         except (Exception, SystemExit) as exc:  # an extra block must not cost the run its line: the failure is reported in its place
