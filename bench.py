@@ -998,23 +998,45 @@ def main():
             v = sorted(ctx.elapsed_ms(a, b) for a, b in e4)
             return v[len(v) // 2], v[0]
 
-        rows4, base4 = [], None
+        def sequence_ms(tn):
+            """(evicting error_estimate, then the call) x reps with TWO events in all: the pair's time, nothing timed in between"""
+            ea4, eb4 = ctx.event(), ctx.event()
+            for i in range(reps4 + 2):
+                if i == 2:
+                    ctx.record(ea4)
+                ctx.error_estimate(normals, P, 0.002, 100, out=evict4)
+                if tn:
+                    ctx.poisson_call(at[:tn], P, f4.thr, ref_code, 100, mode=mode, call_mask=mask4[:tn], capacity=cap, calls_buf=calls_buf, n_calls=n_calls)
+            ctx.record(eb4)
+            torch.cuda.synchronize()
+            return ctx.elapsed_ms(ea4, eb4) / reps4
+
+        evict_only = sequence_ms(0)
+        rows4, base4, base4s = [], None, None
         for n in (1, 2, 4, 8):
             med, mn = shard_ms(T4 // n)
+            seq = sequence_ms(T4 // n) - evict_only  # what the call adds to a stream of work (no event bubbles around it)
             base4 = med if n == 1 else base4
+            base4s = seq if n == 1 else base4s
             rows4.append({"n_gpus": n, "tumours_per_gpu": T4 // n, "poisson_call_ms": med, "min_ms": mn, "efficiency": base4 / n / med,
+                          "poisson_call_ms_in_sequence": seq, "efficiency_in_sequence": base4s / n / seq,
                           "R_VC_evals_per_s_whole_job": P * T4 / (med * 1e-3)})
         if ctx.flags(clear=True) != 0:
             raise SystemExit("kernel flags raised in the tumour-shard projection")
         # t(T) = a + b T through the two end points: the fixed cost of a call and what it does to the eighth
         b4 = (rows4[0]["poisson_call_ms"] - rows4[3]["poisson_call_ms"]) / (T4 - T4 // 8)
         a4 = rows4[3]["poisson_call_ms"] - b4 * (T4 // 8)
+        b4s = (rows4[0]["poisson_call_ms_in_sequence"] - rows4[3]["poisson_call_ms_in_sequence"]) / (T4 - T4 // 8)
         shard_proj = {"workload": CONFIGS["c4"]["name"], "records": layout, "passes_per_size": reps4, "by_n_gpus": rows4,
                       "efficiency_at_8": rows4[3]["efficiency"], "fixed_cost_ms": a4, "ms_per_tumour": b4,
+                      "efficiency_at_8_in_sequence": rows4[3]["efficiency_in_sequence"],
+                      "fixed_cost_ms_in_sequence": rows4[3]["poisson_call_ms_in_sequence"] - b4s * (T4 // 8), "evicting_error_estimate_ms": evict_only,
                       "note": "ONE GPU: poisson_call (stream kernel + drain kernel, HIP events, median) over config 4's first 1024 / N tumours against the same "
                               "call over all 1024, divided by N; every call cold (an error_estimate of this run's normals between two calls).  efficiency = "
                               "t(1024) / N / t(1024 / N).  fixed_cost_ms / ms_per_tumour: the line through the N = 1 and N = 8 points -- the drain's latency "
-                              "chain, two launch gaps and the ramp of a launch do not shrink with the shard (DESIGN 7)"}
+                              "chain, two launch gaps and the ramp of a launch do not shrink with the shard (DESIGN 7).  *_in_sequence: the same calls "
+                              "timed as what they ADD to a stream of work -- (error_estimate, call) x passes between two events minus the "
+                              "error_estimate alone timed the same way -- i.e. without the ~4 us bubble each bracketing event costs"}
         del at, mask4
         torch.cuda.empty_cache()
     sustained = None
